@@ -1,0 +1,180 @@
+/*
+ * smpc.h — C ABI of the MI355X batched social-MPC solver.
+ *
+ * This is the drop-in boundary for ONE hot path of PIC4SeR/nav2_social_mpc_controller:
+ * everything `Optimizer::optimize` does between `project_people(...)` returning and the
+ * `TrajectoryMemory` store, i.e. reference `src/optimizer.cpp:197-446`:
+ *   - problem assembly            (src/optimizer.cpp:241-379)   -> implied by smpc_params + smpc_scene_batch
+ *   - ceres::Solve                (src/optimizer.cpp:381)       -> smpc_solve_batch
+ *   - per-residual functors       (include/.../critics/<critic>_cost_function.hpp, update_state.hpp) -> smpc_eval_batch / inside solve
+ *   - post-solve unpack + re-roll (src/optimizer.cpp:390-446)   -> smpc_result_batch.cmds / .path
+ *
+ * Plain C types only, caller-allocated buffers, no exceptions cross this boundary.
+ * All floating point data are IEEE f64, costmaps are u8 (nav2 `Costmap2D::getCharMap()` layout,
+ * row-major [size_y][size_x]).
+ *
+ * Notation: T = rollout steps (= optim_velocities.size() after pop_back,
+ * src/optimizer.cpp:237), CH = min(control_horizon,T), bl = min(parameter_block_length,CH),
+ * nb = (CH-1)/bl+1 parameter blocks, P = 2*nb unknowns [v_0, w_0, v_1, w_1, ...],
+ * N = agents per step, M = residual count (8T or 5T per-step rows + CH/bl-1 feasibility rows).
+ */
+#ifndef SMPC_H_
+#define SMPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMPC_ABI_VERSION 1
+#define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20 */
+
+/* linear_solver_type: mirrors OptimizerParams::solver_types (optimizer.hpp:71-77). */
+enum smpc_linear_solver {
+  SMPC_DENSE_SCHUR = 0,
+  SMPC_SPARSE_SCHUR = 1,
+  SMPC_DENSE_NORMAL_CHOLESKY = 2,
+  SMPC_DENSE_QR = 3,
+  SMPC_SPARSE_NORMAL_CHOLESKY = 4
+};
+
+/* Per-scene termination, mirrors ceres::TerminationType as far as Optimizer::optimize observes it
+ * (summary.IsSolutionUsable(), src/optimizer.cpp:384). */
+enum smpc_status {
+  SMPC_CONVERGENCE = 0,    /* usable */
+  SMPC_NO_CONVERGENCE = 1, /* usable (iteration cap) */
+  SMPC_FAILURE = 2         /* NOT usable: non-finite initial evaluation or 5 consecutive invalid steps */
+};
+
+/* Reason detail for SMPC_CONVERGENCE / others (diagnostics only). */
+enum smpc_reason {
+  SMPC_REASON_NONE = 0,
+  SMPC_REASON_GRADIENT_TOL = 1,
+  SMPC_REASON_PARAMETER_TOL = 2,
+  SMPC_REASON_FUNCTION_TOL = 3,
+  SMPC_REASON_MIN_RADIUS = 4,
+  SMPC_REASON_MAX_ITERATIONS = 5,
+  SMPC_REASON_INVALID_STEPS = 6,
+  SMPC_REASON_EVAL_FAILED = 7
+};
+
+/* API return codes (never exceptions). */
+enum smpc_error {
+  SMPC_OK = 0,
+  SMPC_ERR_INVALID_ARG = -1,
+  SMPC_ERR_UNSUPPORTED = -2, /* e.g. nb > SMPC_MAX_BLOCKS */
+  SMPC_ERR_DEVICE = -3,      /* HIP runtime error; see smpc_last_error() */
+  SMPC_ERR_NO_DEVICE = -4
+};
+
+/* Mirrors OptimizerParams (optimizer.hpp:59-101) + the constants Optimizer::optimize hard-codes. */
+typedef struct smpc_params {
+  /* weights.* (src/optimizer.cpp:57-75) */
+  double distance_w;
+  double socialwork_w;
+  double velocity_w;
+  double angle_w; /* drives the second DistanceCost (path-align), src/optimizer.cpp:333-334 */
+  double agent_angle_w;
+  double proxemics_w;
+  double velocity_feasibility_w;
+  double obstacle_w;
+  double goal_align_w;
+  /* optimizer.* */
+  int control_horizon;        /* raw parameter; clamped to T per batch */
+  int parameter_block_length; /* raw parameter; clamped to CH */
+  int max_iterations;         /* Solver::Options::max_num_iterations (src/optimizer.cpp:118) */
+  int linear_solver_type;     /* enum smpc_linear_solver */
+  double fn_tol;
+  double gradient_tol;
+  double param_tol;
+  /* constants that are literals in the reference; exposed with the same defaults */
+  double desired_linear_vel; /* 0.6, src/optimizer.cpp:238 */
+  double v_min, v_max;       /* 0.0, 0.6, src/optimizer.cpp:375-376 */
+  double w_min, w_max;       /* -1.4, 1.4, src/optimizer.cpp:377-378 */
+  /* benchmark / diagnostics switches (0 = reference behaviour) */
+  int fixed_iterations; /* !=0: disable the three tolerance tests, run exactly max_iterations LM iterations */
+  int tol_needs_successful_step; /* 0: Ceres 2.0.x order; 1: Ceres >=2.1 (tolerance exits need one accepted step first) */
+} smpc_params;
+
+/* Fill with the reference's code defaults (src/optimizer.cpp:26-82) and hard-coded literals. */
+void smpc_params_default(smpc_params* p);
+
+/* One batch of independent scenes. All scenes share T, N, dt, costmap geometry. */
+typedef struct smpc_scene_batch {
+  int32_t B;         /* scenes */
+  int32_t T;         /* rollout steps */
+  int32_t N;         /* agents per step (reference: exactly 3, padded with t=-1) */
+  int32_t on_device; /* 0: all pointers are host memory; 1: all pointers are device (HBM) memory */
+  double dt;         /* time_step, already widened from float as the reference does (optimizer.hpp:170) */
+
+  const double* pose0;       /* [B][3]  x, y, yaw of evolving_poses[0]                (src/optimizer.cpp:219-226) */
+  const double* init_params; /* [B][P]  initial block values = optim_velocities[0..nb-1] (aliasing quirk, :254-261) */
+  const double* path_pts;    /* [B][T+1][2] optim_positions; [T] is the final trajectorized point (:234-235,327) */
+  const double* goal_yaw;    /* [B]     optim_headings.back().params[1]               (:298) */
+  const double* people;      /* [B][T+1][6][N] people_proj: fields x,y,yaw,t,lv,av; t == -1 marks invalid (:193) */
+  const uint8_t* has_people; /* [B]     people.people.size() != 0                     (:263) */
+
+  const uint8_t* costmap;       /* [B or 1][size_y][size_x] */
+  int32_t costmap_shared;       /* 1: one costmap for all scenes */
+  int32_t size_x, size_y;       /* getSizeInCellsX/Y */
+  const double* costmap_origin; /* [B][2] or [1][2] when shared: getOriginX/Y */
+  double resolution;            /* getResolution */
+} smpc_scene_batch;
+
+typedef struct smpc_result_batch {
+  /* Any pointer may be NULL (that output is skipped). Same memory space as the scene batch. */
+  double* params;       /* [B][P]       optimised block values */
+  double* cmds;         /* [B][T+1][2]  saving_velocities (v, w)                   (src/optimizer.cpp:395-419) */
+  double* path;         /* [B][T+1][3]  re-rolled x, y, yaw; pose0 omitted          (:420-446) */
+  int32_t* status;      /* [B] enum smpc_status */
+  int32_t* reason;      /* [B] enum smpc_reason */
+  int32_t* iterations;  /* [B] LM iterations performed (successful + unsuccessful) */
+  int32_t* evaluations; /* [B] residual+Jacobian sweeps performed */
+  double* initial_cost; /* [B] */
+  double* final_cost;   /* [B] */
+} smpc_result_batch;
+
+/* Outputs of the stand-alone residual/Jacobian sweep (kernel K1), used for parity checks and roofline runs. */
+typedef struct smpc_eval_batch_out {
+  double* residuals; /* [B][M]    reference residual order */
+  double* jacobian;  /* [B][M][P] dense, unscaled */
+  double* cost;      /* [B] 0.5*||r||^2 */
+  double* gradient;  /* [B][P] J^T r */
+} smpc_eval_batch_out;
+
+typedef struct smpc_handle smpc_handle;
+
+/* Problem dimensions implied by (params, T, has_people): fills any non-NULL output. Returns smpc_error. */
+int smpc_dims(const smpc_params* p, int T, int has_people, int* CH, int* bl, int* nb, int* P, int* M,
+              int* n_bounded_blocks);
+
+/* Create a solver bound to HIP device `device`. Fails (NULL, smpc_last_error()) when no device is present:
+ * there is no CPU fallback behind this ABI. */
+smpc_handle* smpc_create(const smpc_params* p, int device);
+void smpc_destroy(smpc_handle* h);
+
+/* Stream the kernels are enqueued on (a hipStream_t passed as void*); NULL = default stream. */
+int smpc_set_stream(smpc_handle* h, void* hip_stream);
+
+/* Solve every scene of the batch: replaces src/optimizer.cpp:241-446 for B scenes at once.
+ * on_device=1: asynchronous on the handle's stream. on_device=0: stages through device memory and
+ * returns after the results are back in host memory. */
+int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* scenes, smpc_result_batch* out);
+
+/* Evaluate residuals / Jacobian at `params` ([B][P], same memory space) — kernel K1 alone. */
+int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* scenes, const double* params,
+                    smpc_eval_batch_out* out);
+
+/* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
+ * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */
+double smpc_last_kernel_ms(smpc_handle* h);
+
+const char* smpc_last_error(void);
+int smpc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMPC_H_ */

@@ -1,0 +1,378 @@
+// smpc_hip.hip — kernels + the C ABI of include/smpc.h (libsmpc_hip.so). gfx950 only, no CPU fallback.
+//
+// Kernels (one 64-lane wavefront = one workgroup = one scene):
+//   smpc_solve_kernel<NB>  whole ceres::Solve-equivalent (reference src/optimizer.cpp:241-446) per scene,
+//                          LM state resident in registers / LDS for all <= max_iterations iterations;
+//   smpc_eval_kernel<NB>   K1: one residual + Jacobian sweep, rows written to HBM (parity + roofline runs).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smpc_lm.hpp"
+
+namespace smpc {
+
+template <int NB>
+__device__ inline bool init_ctx(const KParams& k, Ctx<NB>& c, double* lds) {
+  c.kp = &k;
+  c.scene = blockIdx.x;
+  c.lane = lane_id();
+  c.lds = lds;
+  c.L = make_layout(k.T, k.N, 2 * NB);
+  const size_t s = c.scene;
+  c.has_people = (k.N > 0) && (k.has_people ? k.has_people[s] != 0 : true);
+  c.x0 = k.pose0[3 * s];
+  c.y0 = k.pose0[3 * s + 1];
+  c.yaw0 = k.pose0[3 * s + 2];
+  c.goal_yaw = k.goal_yaw[s];
+  const size_t cm = (size_t)k.size_x * k.size_y;
+  c.map = k.costmap + (k.costmap_shared ? 0 : cm * s);
+  c.ox = k.costmap_origin[k.costmap_shared ? 0 : 2 * s];
+  c.oy = k.costmap_origin[k.costmap_shared ? 1 : 2 * s + 1];
+  c.path_pts = k.path_pts + s * (k.T + 1) * 2;
+  return true;
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void smpc_solve_kernel(const KParams k) {
+  extern __shared__ double lds[];
+  Ctx<NB> c;
+  init_ctx<NB>(k, c, lds);
+  setup_scene<NB>(c);
+  solve_scene<NB>(c);
+}
+
+template <int NB>
+__global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
+  extern __shared__ double lds[];
+  constexpr int P = 2 * NB;
+  Ctx<NB> c;
+  init_ctx<NB>(k, c, lds);
+  setup_scene<NB>(c);
+  double x[P];
+  const size_t s = c.scene;
+#pragma unroll
+  for (int q = 0; q < P; ++q) x[q] = k.e_x[s * P + q];
+  Gram<P> G;
+  bool finite;
+  double* out_r = k.e_residuals ? k.e_residuals + s * k.e_M : nullptr;
+  double* out_J = k.e_jacobian ? k.e_jacobian + s * (size_t)k.e_M * P : nullptr;
+  // rows a scene without people does not have stay zero
+  if (!c.has_people) {
+    const int M5 = 5 * k.T + k.nfeas;
+    for (int i = M5 + c.lane; i < k.e_M; i += kWave) {
+      if (out_r) out_r[i] = 0.0;
+      if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)i * P + q] = 0.0;
+    }
+  }
+  sweep<NB>(c, x, G, finite, out_r, out_J);
+  if (c.lane == 0 && k.e_cost) k.e_cost[s] = 0.5 * G.v[Gram<P>::idx(P, P)];
+  if (k.e_gradient && c.lane < P) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < P; ++q) v = (q == c.lane) ? G.v[Gram<P>::idx(q, P)] : v;
+    k.e_gradient[s * P + c.lane] = v;
+  }
+}
+
+}  // namespace smpc
+
+// ================================================================================================
+// Host side of the C ABI
+// ================================================================================================
+namespace {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string& s) { g_last_error = s; }
+
+#define SMPC_HIP_CHECK(expr)                                                                   \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+      return SMPC_ERR_DEVICE;                                                                  \
+    }                                                                                          \
+  } while (0)
+
+struct Dims { int CH, bl, nb, P, M, nbounded, nfeas; };
+
+Dims make_dims(const smpc_params& p, int T, bool has_people) {
+  Dims d;
+  d.CH = p.control_horizon < T ? p.control_horizon : T;                 // src/optimizer.cpp:248
+  d.bl = p.parameter_block_length < d.CH ? p.parameter_block_length : d.CH;  // :249
+  if (d.bl < 1) d.bl = 1;
+  d.nb = (d.CH - 1) / d.bl + 1;
+  d.P = 2 * d.nb;
+  d.nbounded = d.CH / d.bl;                                             // :373
+  int nf = (d.CH / d.bl < T ? d.CH / d.bl : T) - 1;                      // :364
+  d.nfeas = nf > 0 ? nf : 0;
+  d.M = (has_people ? 8 : 5) * T + d.nfeas;
+  return d;
+}
+
+}  // namespace
+
+struct smpc_handle {
+  smpc_params prm;
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  bool timed;
+};
+
+namespace {
+
+using KernelFn = void (*)(const smpc::KParams);
+
+template <int NB> KernelFn solve_fn() { return smpc::smpc_solve_kernel<NB>; }
+template <int NB> KernelFn eval_fn() { return smpc::smpc_eval_kernel<NB>; }
+
+KernelFn pick(int nb, bool eval) {
+  switch (nb) {
+    case 1: return eval ? eval_fn<1>() : solve_fn<1>();
+    case 2: return eval ? eval_fn<2>() : solve_fn<2>();
+    case 3: return eval ? eval_fn<3>() : solve_fn<3>();
+    case 4: return eval ? eval_fn<4>() : solve_fn<4>();
+    case 5: return eval ? eval_fn<5>() : solve_fn<5>();
+    case 6: return eval ? eval_fn<6>() : solve_fn<6>();
+    default: return nullptr;
+  }
+}
+
+int validate(const smpc_handle* h, const smpc_scene_batch* sb, Dims* d) {
+  if (!h || !sb) { set_error("null handle or scene batch"); return SMPC_ERR_INVALID_ARG; }
+  if (sb->B < 0 || sb->T < 1 || sb->N < 0) { set_error("bad B/T/N"); return SMPC_ERR_INVALID_ARG; }
+  if (h->prm.control_horizon < 1 || h->prm.parameter_block_length < 1) { set_error("control_horizon and parameter_block_length must be >= 1"); return SMPC_ERR_INVALID_ARG; }
+  if (!sb->pose0 || !sb->init_params || !sb->path_pts || !sb->goal_yaw || !sb->costmap || !sb->costmap_origin) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
+  if (sb->N > 0 && !sb->people) { set_error("people is null with N > 0"); return SMPC_ERR_INVALID_ARG; }
+  if (sb->size_x < 1 || sb->size_y < 1 || !(sb->resolution > 0.0)) { set_error("bad costmap geometry"); return SMPC_ERR_INVALID_ARG; }
+  *d = make_dims(h->prm, sb->T, true);
+  if (sb->T + 1 > smpc::kWave) { set_error("T + 1 > 64 rollout poses is not supported by the one-wave-per-scene mapping"); return SMPC_ERR_UNSUPPORTED; }
+  if (sb->N > smpc::kWave) { set_error("N > 64 agents is not supported"); return SMPC_ERR_UNSUPPORTED; }
+  if (!pick(d->nb, false)) { set_error("number of parameter blocks not instantiated (nb must be 1..6)"); return SMPC_ERR_UNSUPPORTED; }
+  return SMPC_OK;
+}
+
+void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& d, smpc::KParams* k) {
+  std::memset(k, 0, sizeof(*k));
+  k->B = sb->B; k->T = sb->T; k->N = sb->N;
+  k->CH = d.CH; k->bl = d.bl; k->nb = d.nb; k->P = d.P; k->nbounded = d.nbounded; k->nfeas = d.nfeas;
+  k->size_x = sb->size_x; k->size_y = sb->size_y; k->costmap_shared = sb->costmap_shared;
+  k->dt = sb->dt; k->resolution = sb->resolution;
+  k->prm = h->prm;
+  k->e_M = d.M;
+}
+
+// Host-pointer batches are staged through device memory by this helper.
+struct Staging {
+  std::vector<void*> allocs;
+  ~Staging() { for (void* p : allocs) (void)hipFree(p); }
+  template <typename T> int up(const T* host, size_t n, const T** dev, hipStream_t st) {
+    *dev = nullptr;
+    if (!host || n == 0) return SMPC_OK;
+    void* p = nullptr;
+    SMPC_HIP_CHECK(hipMalloc(&p, n * sizeof(T)));
+    allocs.push_back(p);
+    SMPC_HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, st));
+    *dev = static_cast<const T*>(p);
+    return SMPC_OK;
+  }
+  template <typename T> int out(T* host, size_t n, T** dev) {
+    *dev = nullptr;
+    if (!host || n == 0) return SMPC_OK;
+    void* p = nullptr;
+    SMPC_HIP_CHECK(hipMalloc(&p, n * sizeof(T)));
+    allocs.push_back(p);
+    *dev = static_cast<T*>(p);
+    return SMPC_OK;
+  }
+};
+
+#define SMPC_TRY(expr) do { int _rc = (expr); if (_rc != SMPC_OK) return _rc; } while (0)
+
+int launch(smpc_handle* h, KernelFn fn, const smpc::KParams& k) {
+  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P);
+  const size_t shmem = (size_t)L.total * sizeof(double);
+  if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
+  if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  if (k.B == 0) return SMPC_OK;
+  SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+  hipLaunchKernelGGL(fn, dim3(k.B), dim3(smpc::kWave), shmem, h->stream, k);
+  SMPC_HIP_CHECK(hipGetLastError());
+  SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  return SMPC_OK;
+}
+
+int bind_inputs(smpc_handle* h, const smpc_scene_batch* sb, const Dims& d, smpc::KParams* k, Staging* st) {
+  const size_t B = sb->B, T = sb->T, N = sb->N;
+  const size_t nmaps = sb->costmap_shared ? 1 : B;
+  if (sb->on_device) {
+    k->pose0 = sb->pose0; k->init_params = sb->init_params; k->path_pts = sb->path_pts; k->goal_yaw = sb->goal_yaw;
+    k->people = sb->people; k->has_people = sb->has_people; k->costmap = sb->costmap; k->costmap_origin = sb->costmap_origin;
+    return SMPC_OK;
+  }
+  SMPC_TRY(st->up(sb->pose0, B * 3, &k->pose0, h->stream));
+  SMPC_TRY(st->up(sb->init_params, B * d.P, &k->init_params, h->stream));
+  SMPC_TRY(st->up(sb->path_pts, B * (T + 1) * 2, &k->path_pts, h->stream));
+  SMPC_TRY(st->up(sb->goal_yaw, B, &k->goal_yaw, h->stream));
+  SMPC_TRY(st->up(sb->people, B * (T + 1) * 6 * N, &k->people, h->stream));
+  SMPC_TRY(st->up(sb->has_people, B, &k->has_people, h->stream));
+  SMPC_TRY(st->up(sb->costmap, nmaps * (size_t)sb->size_x * sb->size_y, &k->costmap, h->stream));
+  SMPC_TRY(st->up(sb->costmap_origin, nmaps * 2, &k->costmap_origin, h->stream));
+  return SMPC_OK;
+}
+
+template <typename T> int down(T* host, const T* dev, size_t n, hipStream_t st) {
+  if (!host || !dev || n == 0) return SMPC_OK;
+  SMPC_HIP_CHECK(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  return SMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smpc_abi_version(void) { return SMPC_ABI_VERSION; }
+
+const char* smpc_last_error(void) { return g_last_error.c_str(); }
+
+void smpc_params_default(smpc_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  // code defaults of OptimizerParams::get, reference src/optimizer.cpp:26-82
+  p->distance_w = 3.0; p->socialwork_w = 1.0; p->velocity_w = 0.5; p->angle_w = 0.0; p->agent_angle_w = 0.5;
+  p->proxemics_w = 90.0; p->velocity_feasibility_w = 0.5; p->obstacle_w = 0.0; p->goal_align_w = 0.0;
+  p->control_horizon = 5; p->parameter_block_length = 5; p->max_iterations = 100;
+  p->linear_solver_type = SMPC_SPARSE_NORMAL_CHOLESKY;
+  p->fn_tol = 1e-7; p->gradient_tol = 1e-10; p->param_tol = 1e-15;
+  // literals of Optimizer::optimize, src/optimizer.cpp:238,375-378
+  p->desired_linear_vel = 0.6; p->v_min = 0.0; p->v_max = 0.6; p->w_min = -1.4; p->w_max = 1.4;
+  p->fixed_iterations = 0; p->tol_needs_successful_step = 0;
+}
+
+int smpc_dims(const smpc_params* p, int T, int has_people, int* CH, int* bl, int* nb, int* P, int* M, int* n_bounded_blocks) {
+  if (!p || T < 1 || p->control_horizon < 1 || p->parameter_block_length < 1) { set_error("bad arguments to smpc_dims"); return SMPC_ERR_INVALID_ARG; }
+  const Dims d = make_dims(*p, T, has_people != 0);
+  if (CH) *CH = d.CH;
+  if (bl) *bl = d.bl;
+  if (nb) *nb = d.nb;
+  if (P) *P = d.P;
+  if (M) *M = d.M;
+  if (n_bounded_blocks) *n_bounded_blocks = d.nbounded;
+  return SMPC_OK;
+}
+
+smpc_handle* smpc_create(const smpc_params* p, int device) {
+  if (!p) { set_error("null params"); return nullptr; }
+  if (p->linear_solver_type < SMPC_DENSE_SCHUR || p->linear_solver_type > SMPC_SPARSE_NORMAL_CHOLESKY) {
+    set_error("Invalid parameter: linear_solver_type");  // same message as reference src/optimizer.cpp:44
+    return nullptr;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) { set_error("no HIP device available (this library has no CPU fallback)"); return nullptr; }
+  if (device < 0 || device >= count) { set_error("device index out of range"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+  smpc_handle* h = new smpc_handle();
+  h->prm = *p;
+  h->device = device;
+  h->stream = nullptr;
+  h->timed = false;
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { set_error("hipEventCreate failed"); delete h; return nullptr; }
+  return h;
+}
+
+void smpc_destroy(smpc_handle* h) {
+  if (!h) return;
+  (void)hipEventDestroy(h->ev0);
+  (void)hipEventDestroy(h->ev1);
+  delete h;
+}
+
+int smpc_set_stream(smpc_handle* h, void* hip_stream) {
+  if (!h) { set_error("null handle"); return SMPC_ERR_INVALID_ARG; }
+  h->stream = static_cast<hipStream_t>(hip_stream);
+  return SMPC_OK;
+}
+
+double smpc_last_kernel_ms(smpc_handle* h) {
+  if (!h || !h->timed) return -1.0;
+  if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_batch* out) {
+  Dims d;
+  SMPC_TRY(validate(h, sb, &d));
+  if (!out) { set_error("null result batch"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  smpc::KParams k;
+  fill_kparams(h, sb, d, &k);
+  Staging st;
+  SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
+  const size_t B = sb->B, T = sb->T;
+  if (sb->on_device) {
+    k.o_params = out->params; k.o_cmds = out->cmds; k.o_path = out->path; k.o_status = out->status; k.o_reason = out->reason;
+    k.o_iterations = out->iterations; k.o_evaluations = out->evaluations; k.o_initial_cost = out->initial_cost; k.o_final_cost = out->final_cost;
+    return launch(h, pick(d.nb, false), k);
+  }
+  SMPC_TRY(st.out(out->params, B * d.P, &k.o_params));
+  SMPC_TRY(st.out(out->cmds, B * (T + 1) * 2, &k.o_cmds));
+  SMPC_TRY(st.out(out->path, B * (T + 1) * 3, &k.o_path));
+  SMPC_TRY(st.out(out->status, B, &k.o_status));
+  SMPC_TRY(st.out(out->reason, B, &k.o_reason));
+  SMPC_TRY(st.out(out->iterations, B, &k.o_iterations));
+  SMPC_TRY(st.out(out->evaluations, B, &k.o_evaluations));
+  SMPC_TRY(st.out(out->initial_cost, B, &k.o_initial_cost));
+  SMPC_TRY(st.out(out->final_cost, B, &k.o_final_cost));
+  SMPC_TRY(launch(h, pick(d.nb, false), k));
+  SMPC_TRY(down(out->params, k.o_params, B * d.P, h->stream));
+  SMPC_TRY(down(out->cmds, k.o_cmds, B * (T + 1) * 2, h->stream));
+  SMPC_TRY(down(out->path, k.o_path, B * (T + 1) * 3, h->stream));
+  SMPC_TRY(down(out->status, k.o_status, B, h->stream));
+  SMPC_TRY(down(out->reason, k.o_reason, B, h->stream));
+  SMPC_TRY(down(out->iterations, k.o_iterations, B, h->stream));
+  SMPC_TRY(down(out->evaluations, k.o_evaluations, B, h->stream));
+  SMPC_TRY(down(out->initial_cost, k.o_initial_cost, B, h->stream));
+  SMPC_TRY(down(out->final_cost, k.o_final_cost, B, h->stream));
+  SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SMPC_OK;
+}
+
+int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* params, smpc_eval_batch_out* out) {
+  Dims d;
+  SMPC_TRY(validate(h, sb, &d));
+  if (!out || !params) { set_error("null params / output"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  smpc::KParams k;
+  fill_kparams(h, sb, d, &k);
+  Staging st;
+  SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
+  const size_t B = sb->B;
+  if (sb->on_device) {
+    k.e_x = params;
+    k.e_residuals = out->residuals; k.e_jacobian = out->jacobian; k.e_cost = out->cost; k.e_gradient = out->gradient;
+    return launch(h, pick(d.nb, true), k);
+  }
+  SMPC_TRY(st.up(params, B * d.P, &k.e_x, h->stream));
+  SMPC_TRY(st.out(out->residuals, B * d.M, &k.e_residuals));
+  SMPC_TRY(st.out(out->jacobian, B * d.M * d.P, &k.e_jacobian));
+  SMPC_TRY(st.out(out->cost, B, &k.e_cost));
+  SMPC_TRY(st.out(out->gradient, B * d.P, &k.e_gradient));
+  SMPC_TRY(launch(h, pick(d.nb, true), k));
+  SMPC_TRY(down(out->residuals, k.e_residuals, B * d.M, h->stream));
+  SMPC_TRY(down(out->jacobian, k.e_jacobian, B * d.M * d.P, h->stream));
+  SMPC_TRY(down(out->cost, k.e_cost, B, h->stream));
+  SMPC_TRY(down(out->gradient, k.e_gradient, B * d.P, h->stream));
+  SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SMPC_OK;
+}
+
+}  // extern "C"

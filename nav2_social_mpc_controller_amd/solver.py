@@ -1,0 +1,172 @@
+"""Python host side above the C ABI (include/smpc.h): loads csrc/libsmpc_hip.so and mirrors the part of the
+reference's `Optimizer` interface that sits on the hot path (optimizer.hpp:152,167-170):
+
+    Optimizer.initialize(OptimizerParams)   -> BatchSolver(params)
+    Optimizer.optimize(...) for B scenes     -> BatchSolver.solve(scenes) / solve_device(...)
+
+There is NO CPU fallback: a missing library or a missing HIP device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import SmpcEvalOut, SmpcParams, SmpcResultBatch, SmpcSceneBatch
+from .params import OptimizerParams
+from .scenes import SceneBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmpc_hip.so")
+_lib = None
+
+
+class SmpcError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libsmpc_hip.so (built by __graft_entry__.build() / csrc/build.sh). Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmpcError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the solver.")
+    lib = C.CDLL(LIB_PATH)
+    lib.smpc_abi_version.restype = C.c_int
+    lib.smpc_last_error.restype = C.c_char_p
+    lib.smpc_params_default.argtypes = [C.POINTER(SmpcParams)]
+    lib.smpc_params_default.restype = None
+    lib.smpc_dims.restype = C.c_int
+    lib.smpc_dims.argtypes = [C.POINTER(SmpcParams), C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 6
+    lib.smpc_create.restype = C.c_void_p
+    lib.smpc_create.argtypes = [C.POINTER(SmpcParams), C.c_int]
+    lib.smpc_destroy.argtypes = [C.c_void_p]
+    lib.smpc_destroy.restype = None
+    lib.smpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.smpc_set_stream.restype = C.c_int
+    lib.smpc_solve_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.POINTER(SmpcResultBatch)]
+    lib.smpc_solve_batch.restype = C.c_int
+    lib.smpc_eval_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.POINTER(SmpcEvalOut)]
+    lib.smpc_eval_batch.restype = C.c_int
+    lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.smpc_last_kernel_ms.restype = C.c_double
+    if lib.smpc_abi_version() != _abi.SMPC_ABI_VERSION:
+        raise SmpcError("libsmpc_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise SmpcError(f"{what} failed ({rc}): {lib.smpc_last_error().decode()}")
+
+
+RESULT_FIELDS = ("params", "cmds", "path", "status", "reason", "iterations", "evaluations", "initial_cost", "final_cost")
+
+
+class BatchSolver:
+    """One solver bound to one HIP device; mirrors Optimizer::initialize + Optimizer::optimize for B scenes."""
+
+    def __init__(self, params: OptimizerParams, device: int = 0):
+        self.lib = load_library()
+        self.params = params
+        self._cparams = params.to_c()
+        self._h = self.lib.smpc_create(C.byref(self._cparams), int(device))
+        if not self._h:
+            raise SmpcError(f"smpc_create failed: {self.lib.smpc_last_error().decode()}")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.smpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        _check(self.lib, self.lib.smpc_set_stream(self._h, C.c_void_p(stream_ptr)), "smpc_set_stream")
+
+    def last_kernel_ms(self) -> float:
+        return float(self.lib.smpc_last_kernel_ms(self._h))
+
+    # -- host-memory path (stages through HBM inside the library) ---------------------------------
+    def solve(self, scenes: SceneBatch):
+        CH, bl, nb, P, M, _ = self.params.dims(scenes.T, True)
+        scenes.validate(P)
+        B, T = scenes.B, scenes.T
+        out = {
+            "params": np.zeros((B, P)), "cmds": np.zeros((B, T + 1, 2)), "path": np.zeros((B, T + 1, 3)),
+            "status": np.zeros(B, np.int32), "reason": np.zeros(B, np.int32), "iterations": np.zeros(B, np.int32),
+            "evaluations": np.zeros(B, np.int32), "initial_cost": np.zeros(B), "final_cost": np.zeros(B),
+        }
+        rb = SmpcResultBatch()
+        for k, v in out.items():
+            setattr(rb, k, v.ctypes.data)
+        sb = scenes.to_c()
+        _check(self.lib, self.lib.smpc_solve_batch(self._h, C.byref(sb), C.byref(rb)), "smpc_solve_batch")
+        return out
+
+    def evaluate(self, scenes: SceneBatch, x: np.ndarray):
+        CH, bl, nb, P, M, _ = self.params.dims(scenes.T, True)
+        scenes.validate(P)
+        B = scenes.B
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (B, P)
+        out = {"residuals": np.zeros((B, M)), "jacobian": np.zeros((B, M, P)), "cost": np.zeros(B),
+               "gradient": np.zeros((B, P))}
+        eo = SmpcEvalOut()
+        for k, v in out.items():
+            setattr(eo, k, v.ctypes.data)
+        sb = scenes.to_c()
+        _check(self.lib, self.lib.smpc_eval_batch(self._h, C.byref(sb), x.ctypes.data, C.byref(eo)), "smpc_eval_batch")
+        return out
+
+    # -- device-resident path (inputs already in HBM; asynchronous on the handle's stream) -------
+    def alloc_results(self, B: int, T: int, device="cuda:0"):
+        import torch
+
+        CH, bl, nb, P, M, _ = self.params.dims(T, True)
+        t = {
+            "params": torch.empty((B, P), dtype=torch.float64, device=device),
+            "cmds": torch.empty((B, T + 1, 2), dtype=torch.float64, device=device),
+            "path": torch.empty((B, T + 1, 3), dtype=torch.float64, device=device),
+            "status": torch.empty(B, dtype=torch.int32, device=device),
+            "reason": torch.empty(B, dtype=torch.int32, device=device),
+            "iterations": torch.empty(B, dtype=torch.int32, device=device),
+            "evaluations": torch.empty(B, dtype=torch.int32, device=device),
+            "initial_cost": torch.empty(B, dtype=torch.float64, device=device),
+            "final_cost": torch.empty(B, dtype=torch.float64, device=device),
+        }
+        rb = SmpcResultBatch()
+        for k, v in t.items():
+            setattr(rb, k, v.data_ptr())
+        return rb, t
+
+    def solve_device(self, sb: SmpcSceneBatch, rb: SmpcResultBatch):
+        assert sb.on_device == 1
+        _check(self.lib, self.lib.smpc_solve_batch(self._h, C.byref(sb), C.byref(rb)), "smpc_solve_batch")
+
+    def alloc_eval(self, B: int, T: int, device="cuda:0"):
+        import torch
+
+        CH, bl, nb, P, M, _ = self.params.dims(T, True)
+        t = {
+            "residuals": torch.empty((B, M), dtype=torch.float64, device=device),
+            "jacobian": torch.empty((B, M, P), dtype=torch.float64, device=device),
+            "cost": torch.empty(B, dtype=torch.float64, device=device),
+            "gradient": torch.empty((B, P), dtype=torch.float64, device=device),
+        }
+        eo = SmpcEvalOut()
+        for k, v in t.items():
+            setattr(eo, k, v.data_ptr())
+        return eo, t
+
+    def eval_device(self, sb: SmpcSceneBatch, x_ptr: int, eo: SmpcEvalOut):
+        assert sb.on_device == 1
+        _check(self.lib, self.lib.smpc_eval_batch(self._h, C.byref(sb), C.c_void_p(x_ptr), C.byref(eo)), "smpc_eval_batch")

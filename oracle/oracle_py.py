@@ -1,0 +1,89 @@
+"""ctypes loader for the CPU oracle (oracle/smpc_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+Never import this from nav2_social_mpc_controller_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from nav2_social_mpc_controller_amd._abi import SmpcEvalOut, SmpcParams, SmpcResultBatch, SmpcSceneBatch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libsmpc_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.smpc_oracle_solve_batch.restype = C.c_int
+        _lib.smpc_oracle_solve_batch.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch),
+                                                 C.POINTER(SmpcResultBatch), C.c_int]
+        _lib.smpc_oracle_eval_batch.restype = C.c_int
+        _lib.smpc_oracle_eval_batch.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch), C.c_void_p,
+                                                C.POINTER(SmpcEvalOut)]
+        _lib.smpc_oracle_solve_trace.restype = C.c_int
+        _lib.smpc_oracle_solve_trace.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch), C.c_int,
+                                                 C.c_void_p, C.c_int, C.c_void_p]
+    return _lib
+
+
+def solve(params, scenes, nthreads=1):
+    """Solve every scene with the CPU oracle. Returns a dict of numpy arrays (same fields as smpc_result_batch)."""
+    CH, bl, nb, P, M, _ = params.dims(scenes.T, True)
+    B, T = scenes.B, scenes.T
+    out = {
+        "params": np.zeros((B, P)), "cmds": np.zeros((B, T + 1, 2)), "path": np.zeros((B, T + 1, 3)),
+        "status": np.zeros(B, np.int32), "reason": np.zeros(B, np.int32), "iterations": np.zeros(B, np.int32),
+        "evaluations": np.zeros(B, np.int32), "initial_cost": np.zeros(B), "final_cost": np.zeros(B),
+    }
+    rb = SmpcResultBatch()
+    for k, v in out.items():
+        setattr(rb, k, v.ctypes.data)
+    cp, sb = params.to_c(), scenes.to_c()
+    rc = lib().smpc_oracle_solve_batch(C.byref(cp), C.byref(sb), C.byref(rb), int(nthreads))
+    if rc != 0:
+        raise RuntimeError(f"smpc_oracle_solve_batch failed: {rc}")
+    return out
+
+
+def evaluate(params, scenes, x, jacobian=True):
+    """Residuals / Jacobian / cost / gradient of every scene at parameters x [B,P]."""
+    CH, bl, nb, P, M, _ = params.dims(scenes.T, True)
+    B = scenes.B
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    assert x.shape == (B, P)
+    out = {"residuals": np.zeros((B, M)), "cost": np.zeros(B)}
+    if jacobian:
+        out["jacobian"] = np.zeros((B, M, P))
+        out["gradient"] = np.zeros((B, P))
+    eo = SmpcEvalOut()
+    for k, v in out.items():
+        setattr(eo, k, v.ctypes.data)
+    cp, sb = params.to_c(), scenes.to_c()
+    rc = lib().smpc_oracle_eval_batch(C.byref(cp), C.byref(sb), x.ctypes.data, C.byref(eo))
+    if rc != 0:
+        raise RuntimeError(f"smpc_oracle_eval_batch failed: {rc}")
+    return out
+
+
+TRACE_COLS = ["iter", "cost", "cost_change", "gradient_max_norm", "step_norm", "rho", "radius", "ls_evals", "accepted"]
+
+
+def trace(params, scenes, scene=0, max_rows=256):
+    rows = np.zeros((max_rows, 9))
+    cp, sb = params.to_c(), scenes.to_c()
+    n = lib().smpc_oracle_solve_trace(C.byref(cp), C.byref(sb), int(scene), rows.ctypes.data, max_rows, None)
+    if n < 0:
+        raise RuntimeError(f"smpc_oracle_solve_trace failed: {n}")
+    return rows[:min(n, max_rows)]
