@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — MPC solves/sec of the batched social-MPC hot path on N MI355X GPUs of one node.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched through
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL). One "step" = one batched solve
+(smpc_solve_batch) of the per-GPU batch of synthetic crowd scenes with all inputs already resident in HBM.
+Weak scaling: every rank owns its own 8192 scenes (BASELINE.json configs[2] per GPU; configs[3] = 8 GPUs x 8192),
+regenerated from (seed, scene_id) — the path shards with no data-path collective.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_sweep(N, T, P, M):
+    """every input read once, J and r written once, per scene per sweep."""
+    return 8 * (6 * N * T + 2 * (T + 1) + P + 5) + 16 * T + 8 * (M * P + M)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8192, help="scenes per GPU")
+    ap.add_argument("--people", type=int, default=8)
+    ap.add_argument("--fixed-iterations", type=int, default=0, help="1: run exactly 40 LM iterations per scene")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from nav2_social_mpc_controller_amd import dist as D
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.scenes import make_scenes
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+
+    rank, local_rank, world = D.env_rank_world()
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    prm = OptimizerParams.readme().replace(fixed_iterations=args.fixed_iterations)
+    B, N = args.batch, args.people
+    lo, hi = D.weak_shard(B, rank)
+    scenes = make_scenes(prm, B, N, seed=0x5EED0001, first_scene=lo)
+    T = scenes.T
+    CH, bl, nb, P, M, _ = prm.dims(T, True)
+
+    solver = BatchSolver(prm, device=local_rank)
+    stream = torch.cuda.Stream(device=device)
+    solver.set_stream(stream.cuda_stream)
+    sb, tens = scenes.to_device(device)
+    rb, out = solver.alloc_results(B, T, device)
+    eo, eout = solver.alloc_eval(B, T, device)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        solver.solve_device(sb, rb)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.solve_device(sb, rb)
+        kernel_ms.append(None)   # duration read after the timed region (event pairs are per launch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # per-launch device time of the solve kernel, HIP events on the kernel's own stream (last launch)
+    solve_ms = solver.last_kernel_ms()
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed_max = float(tmax.item())
+
+    evals = out["evaluations"].cpu().numpy().astype(np.int64)
+    iters = out["iterations"].cpu().numpy()
+    status = out["status"].cpu().numpy()
+    local = {"scenes": B, "sweeps": int(evals.sum()), "iterations": int(iters.sum()),
+             "converged": int((status == 0).sum()), "no_convergence": int((status == 1).sum()),
+             "failed": int((status == 2).sum()), "max_solve_kernel_ms": solve_ms}
+    summ = D.reduce_summary(local, device=device)
+
+    # K1 stand-alone sweep (residual + Jacobian rows written to HBM) for the roofline line
+    for _ in range(3):
+        solver.eval_device(sb, tens["init_params"].data_ptr(), eo)
+    k1_ms = solver.last_kernel_ms()
+
+    if rank == 0:
+        total_solves = summ["scenes"] * args.steps
+        value = total_solves / elapsed_max
+        bytes_sweep = algorithmic_bytes_per_sweep(N, T, P, M)
+        sweeps_per_launch = int(evals.sum())
+        achieved = sweeps_per_launch * bytes_sweep / (solve_ms * 1e-3) / 1e9
+        k1_achieved = B * bytes_sweep / (k1_ms * 1e-3) / 1e9
+        line = {
+            "metric": "MPC solves/sec (horizon=18, 8 agents, 40 iters)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2] per GPU: batch={B} scenes/GPU, {N} people, horizon=18 "
+                                   f"(T={T}, block=6, P={P}, M={M}), 200x200 u8 costmap per scene, DENSE_SCHUR, "
+                                   f"max 40 LM iterations with Ceres termination rules"
+                                   + (" DISABLED (fixed 40 iterations)" if args.fixed_iterations else ""),
+                       "scenes_per_gpu": B, "people": N, "T": T, "P": P, "M": M,
+                       "mean_lm_iterations": summ["iterations"] / summ["scenes"],
+                       "mean_sweeps_per_solve": summ["sweeps"] / summ["scenes"],
+                       "status": {"convergence": int(summ["converged"]), "no_convergence": int(summ["no_convergence"]),
+                                  "failure": int(summ["failed"])}},
+            "roofline": {"bound": "hbm", "kernel": "smpc_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launch_ms": solve_ms, "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
+                         "k1_sweep_kernel": {"launch_ms": k1_ms, "achieved": k1_achieved, "frac": k1_achieved / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py as O
+            cores = os.cpu_count() or 1
+            n_sample = min(B, 32 * cores)
+            sample = scenes.select(np.arange(n_sample))
+            t1 = time.perf_counter()
+            ref = O.solve(prm, sample, nthreads=cores)
+            cpu_s = time.perf_counter() - t1
+            got = out["cmds"][:n_sample].cpu().numpy()
+            dcmd = np.abs(got - ref["cmds"]).reshape(n_sample, -1).max(axis=1)
+            line["cpu_baseline"] = {"value": n_sample / cpu_s, "unit": "solves/s", "cores": cores, "kind": "port",
+                                    "sample": f"first {n_sample} scenes of the same workload, one solve per thread "
+                                              f"(CPU restatement oracle/smpc_oracle.cpp, not Ceres), {cpu_s:.1f} s"}
+            line["parity"] = {"scenes": int(n_sample), "max_abs_dcmd": float(dcmd.max()),
+                              "median_abs_dcmd": float(np.median(dcmd)), "scenes_over_1e-5": int((dcmd > 1e-5).sum())}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): built on demand from oracle/smpc_oracle.cpp."""
+    from oracle import oracle_py
+    oracle_py.lib()
+    return oracle_py
+
+
+def load_golden(name):
+    """(params, scenes, expected dict) of one committed fixture (tests/golden/make_golden.py)."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.scenes import SceneBatch
+
+    exp = dict(np.load(os.path.join(GOLDEN, f"{name}_expected.npz"), allow_pickle=False))
+    kw = {}
+    for k in list(exp):
+        if k.startswith("prm_"):
+            v = exp.pop(k)
+            kw[k[4:]] = v.item() if v.shape == () else v
+    for k, v in kw.items():
+        if isinstance(v, (np.str_, str)):
+            kw[k] = str(v)
+    prm = OptimizerParams(**kw)
+    sc = SceneBatch.load(os.path.join(GOLDEN, f"{name}_scenes.npz"))
+    return prm, sc, exp
+
+
+GOLDEN_CASES = ["ref_n3_phantom", "cfg3_n8", "params_yaml_n3", "cfg1_nopeople_qr", "quirk_unbounded_last_block"]
+
+
+def cmd_err(a, b):
+    """max |delta cmd| per scene."""
+    return np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
+
+
+def yaw_err(a, b):
+    d = a - b
+    return np.abs(np.arctan2(np.sin(d), np.cos(d)))

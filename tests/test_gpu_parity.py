@@ -1,0 +1,194 @@
+"""GPU parity tests proper (`-m gpu`): every call goes through the C ABI (libsmpc_hip.so); the CPU oracle and
+the committed golden fixtures are the checkers. Tolerance: max |delta cmd| <= 1e-5 on the optimised command
+sequence (BASELINE.json north_star), everything f64."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, cmd_err, load_golden, yaw_err
+from nav2_social_mpc_controller_amd.params import OptimizerParams
+from nav2_social_mpc_controller_amd.scenes import make_scenes
+
+pytestmark = pytest.mark.gpu
+
+CMD_TOL = 1e-5      # north_star: outputs match the reference solve within 1e-5 on the optimised command sequence
+JAC_RTOL = 1e-9     # K1 rows vs the dual-number oracle, relative to max(1, |value|)
+
+
+@pytest.fixture(scope="module")
+def Solver():
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    return BatchSolver
+
+
+README = OptimizerParams.readme()
+EVAL_CASES = {
+    "ref_n3_phantom": (README, dict(B=64, N=3, n_valid=2, map_cells=80, seed=101)),
+    "cfg2_n4": (README, dict(B=64, N=4, seed=102)),
+    "cfg3_n8": (README, dict(B=64, N=8, seed=103)),
+    "cfg5_n16_h30": (README.replace(control_horizon=30, max_time=2.0), dict(B=32, N=16, seed=104)),
+    "params_yaml_n3": (OptimizerParams.params_yaml(), dict(B=32, N=3, seed=105)),
+    "cfg1_nopeople": (OptimizerParams.params_yaml().replace(control_horizon=18, linear_solver_type="DENSE_QR"),
+                      dict(B=32, N=3, seed=106, people_present=False)),
+    "quirk_bl_not_dividing_ch": (README.replace(time_step=0.1), dict(B=32, N=3, seed=107)),
+    "all_agents_invalid": (README, dict(B=16, N=3, n_valid=0, seed=108)),
+    "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=16, N=5, seed=109)),
+}
+
+
+@pytest.mark.parametrize("name", list(EVAL_CASES))
+def test_k1_rows_match_oracle(Solver, oracle, name):
+    prm, kw = EVAL_CASES[name]
+    sc = make_scenes(prm, **kw)
+    s = Solver(prm)
+    rng = np.random.default_rng(3)
+    for x in (sc.init_params, sc.init_params + 0.05 * rng.standard_normal(sc.init_params.shape)):
+        eo = oracle.evaluate(prm, sc, x)
+        eg = s.evaluate(sc, x)
+        for key, tol in (("residuals", JAC_RTOL), ("jacobian", JAC_RTOL), ("gradient", 1e-8)):
+            err = np.abs(eo[key] - eg[key]) / np.maximum(1.0, np.abs(eo[key]))
+            assert np.max(err) < tol, (key, float(np.max(err)))
+        assert np.max(np.abs(eo["cost"] - eg["cost"]) / np.maximum(1.0, eo["cost"])) < 1e-11
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_solve_matches_committed_golden(Solver, name):
+    prm, sc, exp = load_golden(name)
+    res = Solver(prm).solve(sc)
+    assert np.max(cmd_err(res["cmds"], exp["oracle_cmds"])) <= CMD_TOL
+    assert np.max(np.abs(res["params"] - exp["oracle_params"])) <= CMD_TOL
+    assert res["status"].tolist() == exp["oracle_status"].tolist()
+    assert res["iterations"].tolist() == exp["oracle_iterations"].tolist()
+    assert np.max(np.abs(res["path"][:, :, :2] - exp["oracle_path"][:, :, :2])) <= 1e-5
+    assert np.max(yaw_err(res["path"][:, :, 2], exp["oracle_path"][:, :, 2])) <= 1e-5
+    assert np.allclose(res["final_cost"], exp["oracle_final_cost"], rtol=1e-8)
+    # ... and against the independent Python restatement's optimum
+    n = exp["pyref_x"].shape[0]
+    assert np.max(np.abs(res["params"][:n] - exp["pyref_x"])) <= CMD_TOL
+
+
+SOLVE_CASES = {
+    "ref_n3_phantom": (README, dict(B=256, N=3, n_valid=2, map_cells=80, seed=201)),
+    "cfg2_n4": (README, dict(B=512, N=4, seed=202)),
+    "cfg3_n8": (README, dict(B=512, N=8, seed=203)),
+    "cfg5_n16_h30": (README.replace(control_horizon=30, max_time=2.0), dict(B=128, N=16, seed=204)),
+    "params_yaml_n3": (OptimizerParams.params_yaml(), dict(B=128, N=3, seed=205)),
+    "cfg1_nopeople_qr": (OptimizerParams.params_yaml().replace(control_horizon=18, linear_solver_type="DENSE_QR"),
+                         dict(B=128, N=3, seed=206, people_present=False)),
+    "quirk_bl_not_dividing_ch": (README.replace(time_step=0.1), dict(B=128, N=3, seed=207)),
+    "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=64, N=5, seed=209)),
+}
+
+
+@pytest.mark.parametrize("name", list(SOLVE_CASES))
+def test_solve_matches_oracle_on_seeded_scenes(Solver, oracle, name):
+    prm, kw = SOLVE_CASES[name]
+    sc = make_scenes(prm, **kw)
+    ro = oracle.solve(prm, sc, nthreads=16)
+    rg = Solver(prm).solve(sc)
+    err = cmd_err(rg["cmds"], ro["cmds"])
+    bad = err > CMD_TOL
+    # The reference objective is discontinuous (sign(theta) in the social force, critics/social_work_cost_function.hpp:210):
+    # a last-ulp libm difference can flip an accept/reject decision. Such scenes are counted,
+    # must stay rare, and must still land on an equally good local optimum.
+    assert bad.mean() <= 0.02, f"{bad.sum()}/{len(bad)} scenes beyond {CMD_TOL}"
+    ok = ~bad
+    assert np.array_equal(rg["status"][ok], ro["status"][ok])
+    assert np.array_equal(rg["iterations"][ok], ro["iterations"][ok])
+    assert np.max(np.abs(rg["path"][ok][:, :, :2] - ro["path"][ok][:, :, :2]), initial=0.0) <= 1e-5
+    if bad.any():
+        rel = (rg["final_cost"][bad] - ro["final_cost"][bad]) / ro["final_cost"][bad]
+        assert np.median(np.abs(rel)) < 0.05
+
+
+def test_moving_crowd_has_no_divergent_scene(Solver, oracle):
+    """Without standing agents the sign(theta) discontinuity is never hit at theta == 0: every scene must agree."""
+    sc = make_scenes(README, 512, 8, seed=301, standing_fraction=0.0)
+    ro = oracle.solve(README, sc, nthreads=16)
+    rg = Solver(README).solve(sc)
+    assert np.max(cmd_err(rg["cmds"], ro["cmds"])) <= CMD_TOL
+    assert np.array_equal(rg["iterations"], ro["iterations"])
+
+
+def test_full_size_properties_cfg3(Solver):
+    """BASELINE config 3 at full size (B=8192, N=8, 200x200 maps): size-independent properties."""
+    prm = README
+    sc = make_scenes(prm, 8192, 8, seed=0x5EED0001)
+    s = Solver(prm)
+    a = s.solve(sc)
+    b = s.solve(sc)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"non-deterministic output {k}"           # idempotent / deterministic
+    CH, bl, nb, P, M, nbnd = prm.dims(sc.T)
+    assert np.all(a["status"] != 2)
+    assert np.all(a["final_cost"] <= a["initial_cost"] * (1 + 1e-12))
+    assert np.all((a["iterations"] >= 0) & (a["iterations"] <= prm.max_iterations))
+    v, w = a["params"][:, 0::2], a["params"][:, 1::2]
+    assert v.min() >= prm.v_min and v.max() <= prm.v_max and w.min() >= prm.w_min and w.max() <= prm.w_max
+    T = sc.T
+    for i in range(T + 1):                                                              # a12 expansion
+        blk = i // bl if i < CH else (CH - 1) // bl
+        assert np.array_equal(a["cmds"][:, i, 0], a["params"][:, 2 * blk])
+        assert np.array_equal(a["cmds"][:, i, 1], a["params"][:, 2 * blk + 1])
+    # re-solving from the optimum must not move it by more than the tolerance band and must not raise the cost
+    sc2 = sc.select(np.arange(0, 8192, 16))
+    sc2.init_params = np.ascontiguousarray(a["params"][::16])
+    r2 = s.solve(sc2)
+    assert np.all(r2["final_cost"] <= a["final_cost"][::16] * (1 + 1e-9))
+    # initial cost reported by the solve == cost of the K1 sweep at the projected start point
+    x0 = np.clip(sc2.init_params, [prm.v_min, prm.w_min] * nb, [prm.v_max, prm.w_max] * nb)
+    ev = s.evaluate(sc2, x0)
+    assert np.allclose(ev["cost"], r2["initial_cost"], rtol=1e-12)
+
+
+def test_edge_cases(Solver, oracle):
+    prm = README
+    s = Solver(prm)
+    # B = 1 (the plugin's use) and B = 0 (empty batch)
+    one = make_scenes(prm, 1, 3, n_valid=3, map_cells=80, seed=401)
+    assert np.max(cmd_err(s.solve(one)["cmds"], oracle.solve(prm, one)["cmds"])) <= CMD_TOL
+    empty = one.select(np.array([], dtype=np.int64))
+    out = s.solve(empty)
+    assert out["cmds"].shape[0] == 0
+    # very short horizon: T = 2 < control_horizon
+    short = make_scenes(prm, 8, 3, T=2, map_cells=80, seed=402, standing_fraction=0.0)
+    assert np.max(cmd_err(s.solve(short)["cmds"], oracle.solve(prm, short)["cmds"])) <= CMD_TOL
+    # robot driving off the costmap: clamp-to-edge interpolation
+    edge = make_scenes(prm, 8, 3, map_cells=20, seed=403, standing_fraction=0.0)
+    assert np.max(cmd_err(s.solve(edge)["cmds"], oracle.solve(prm, edge)["cmds"])) <= CMD_TOL
+    # shared costmap
+    shared = make_scenes(prm, 8, 4, map_cells=80, seed=404, standing_fraction=0.0)
+    shared.costmap = np.ascontiguousarray(shared.costmap[:1]); shared.costmap_origin = np.ascontiguousarray(shared.costmap_origin[:1])
+    shared.costmap_shared = True
+    assert np.max(cmd_err(s.solve(shared)["cmds"], oracle.solve(prm, shared)["cmds"])) <= CMD_TOL
+    # iteration cap 0: parameters are only projected into the box
+    capped = Solver(prm.replace(max_iterations=0)).solve(one)
+    assert capped["iterations"][0] == 0 and capped["status"][0] == 1
+    # unsupported shapes are refused with an error code, not a crash
+    from nav2_social_mpc_controller_amd.solver import SmpcError
+    too_long = make_scenes(prm, 1, 3, T=70, map_cells=40, seed=405)
+    with pytest.raises(SmpcError):
+        s.solve(too_long)
+
+
+def test_fixed_iteration_mode_runs_all_iterations(Solver):
+    prm = README.replace(fixed_iterations=1)
+    sc = make_scenes(prm, 64, 8, seed=501)
+    r = Solver(prm).solve(sc)
+    assert np.all((r["iterations"] == prm.max_iterations) | (r["reason"] == 4) | (r["reason"] == 6))
+
+
+def test_device_resident_path_matches_host_path(Solver):
+    import torch
+    prm = README
+    sc = make_scenes(prm, 256, 8, seed=601)
+    s = Solver(prm)
+    host = s.solve(sc)
+    sb, tens = sc.to_device()
+    rb, rt = s.alloc_results(sc.B, sc.T)
+    stream = torch.cuda.Stream()
+    s.set_stream(stream.cuda_stream)
+    s.solve_device(sb, rb)
+    stream.synchronize()
+    assert s.last_kernel_ms() > 0.0
+    for k in host:
+        assert np.array_equal(rt[k].cpu().numpy(), host[k]), k

@@ -1,0 +1,156 @@
+"""CPU tests of the oracle (oracle/smpc_oracle.cpp): against the committed golden vectors produced by the
+independent Python restatement (oracle/pyref.py), plus LM properties and the reference quirks of SURVEY §8a.
+
+PARITY UNPINNED: the reference holds no fixtures and Ceres is absent; these tests pin the oracle to a second,
+independently written restatement of the same specification, not to the reference binary."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, cmd_err, load_golden, yaw_err
+from nav2_social_mpc_controller_amd.params import OptimizerParams
+from nav2_social_mpc_controller_amd.scenes import make_scenes
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_residuals_and_jacobian_match_pyref_golden(oracle, name):
+    prm, sc, exp = load_golden(name)
+    ev = oracle.evaluate(prm, sc, sc.init_params)
+    scale_r = np.maximum(1.0, np.abs(exp["pyref_residuals"]))
+    scale_j = np.maximum(1.0, np.abs(exp["pyref_jacobian"]))
+    assert np.max(np.abs(ev["residuals"] - exp["pyref_residuals"]) / scale_r) < 1e-10
+    assert np.max(np.abs(ev["jacobian"] - exp["pyref_jacobian"]) / scale_j) < 1e-9
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_solve_matches_pyref_golden(oracle, name):
+    """Same LM trajectory: iteration count and optimum agree with the numpy LM restatement."""
+    prm, sc, exp = load_golden(name)
+    res = oracle.solve(prm, sc)
+    n = exp["pyref_x"].shape[0]
+    assert np.max(np.abs(res["params"][:n] - exp["pyref_x"])) < 1e-7      # north-star tolerance is 1e-5
+    assert res["iterations"][:n].tolist() == exp["pyref_iterations"].tolist()
+    assert np.allclose(res["final_cost"][:n], exp["pyref_cost"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_oracle_reproduces_its_own_golden(oracle, name):
+    """Guards the committed oracle outputs the GPU tests compare against (detects accidental oracle changes)."""
+    prm, sc, exp = load_golden(name)
+    res = oracle.solve(prm, sc)
+    assert np.max(cmd_err(res["cmds"], exp["oracle_cmds"])) < 1e-9
+    assert res["iterations"].tolist() == exp["oracle_iterations"].tolist()
+    assert res["status"].tolist() == exp["oracle_status"].tolist()
+
+
+def test_jacobian_matches_central_differences(oracle):
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 3, 4, map_cells=80, seed=5)
+    x = sc.init_params + 0.01
+    ev = oracle.evaluate(prm, sc, x)
+    h = 1e-6
+    P = x.shape[1]
+    for q in range(P):
+        xp, xm = x.copy(), x.copy()
+        xp[:, q] += h
+        xm[:, q] -= h
+        fd = (oracle.evaluate(prm, sc, xp, jacobian=False)["residuals"] - oracle.evaluate(prm, sc, xm, jacobian=False)["residuals"]) / (2 * h)
+        an = ev["jacobian"][:, :, q]
+        # the bicubic costmap term is only C1: finite differences are accurate to ~h there
+        assert np.max(np.abs(fd - an) / np.maximum(1.0, np.abs(an))) < 5e-4
+
+
+def test_lm_properties(oracle):
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 32, 8, map_cells=80, seed=7)
+    res = oracle.solve(prm, sc, nthreads=8)
+    CH, bl, nb, P, M, nbnd = prm.dims(sc.T)
+    assert np.all(res["status"] != 2)                               # usable (CONVERGENCE / NO_CONVERGENCE)
+    assert np.all(res["final_cost"] <= res["initial_cost"] * (1 + 1e-12))
+    assert np.all(res["iterations"] <= prm.max_iterations)
+    v, w = res["params"][:, 0::2], res["params"][:, 1::2]
+    assert np.all(v >= prm.v_min) and np.all(v <= prm.v_max)        # all 3 blocks bounded at H18/bl6
+    assert np.all(w >= prm.w_min) and np.all(w <= prm.w_max)
+    # every accepted step decreases the cost (monotonic trust region)
+    tr = oracle.trace(prm, sc, 0)
+    acc = tr[tr[:, 8] == 1.0]
+    assert np.all(np.diff(acc[:, 1]) < 0)
+
+
+def test_unpack_quirks(oracle):
+    """a12: cmds has T+1 entries, block i/bl for i<CH then the last block; path omits pose0 and has T+1 poses."""
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 4, 3, map_cells=80, seed=9)
+    res = oracle.solve(prm, sc)
+    CH, bl, nb, P, M, nbnd = prm.dims(sc.T)
+    T = sc.T
+    assert res["cmds"].shape == (4, T + 1, 2) and res["path"].shape == (4, T + 1, 3)
+    for i in range(T + 1):
+        b = i // bl if i < CH else (CH - 1) // bl
+        assert np.array_equal(res["cmds"][:, i, 0], res["params"][:, 2 * b])
+        assert np.array_equal(res["cmds"][:, i, 1], res["params"][:, 2 * b + 1])
+    # first output pose is pose0 advanced by one step
+    x1 = sc.pose0[:, 0] + res["cmds"][:, 0, 0] * np.cos(sc.pose0[:, 2]) * sc.dt
+    assert np.allclose(res["path"][:, 0, 0], x1, atol=1e-12)
+
+
+def test_quirk_last_block_unbounded_when_bl_does_not_divide_ch(oracle):
+    """a10-ii: dt=0.1 -> T=13, CH=13, bl=6: 3 blocks, only CH/bl=2 bounded, 1 feasibility row."""
+    prm = OptimizerParams.readme().replace(time_step=0.1)
+    assert prm.rollout_steps == 13
+    assert prm.dims(13) == (13, 6, 3, 6, 8 * 13 + 1, 2)
+    sc = make_scenes(prm, 16, 3, map_cells=80, seed=15)
+    # start the unbounded block outside the box: it must not be projected
+    sc.init_params[:, 4] = 0.9
+    res = oracle.solve(prm.replace(max_iterations=0), sc)
+    assert np.all(res["params"][:, 4] == 0.9)
+    sc.init_params[:, 0] = 0.9                                      # bounded block IS projected before iteration 0
+    res = oracle.solve(prm.replace(max_iterations=0), sc)
+    assert np.all(res["params"][:, 0] == prm.v_max)
+
+
+def test_quirk_phantom_agents_contribute_to_social_work(oracle):
+    """a3-i: invalid agents (t=-1, at the origin) are skipped as 'others' but still looped over as 'me' in wp."""
+    prm = OptimizerParams.readme()
+    sc2 = make_scenes(prm, 2, 3, n_valid=2, map_cells=80, seed=21)
+    r_pad = oracle.evaluate(prm, sc2, sc2.init_params, jacobian=False)["residuals"]
+    # same scene with the phantom column physically removed (N=2): social rows differ, every other row is equal
+    sc1 = make_scenes(prm, 2, 3, n_valid=2, map_cells=80, seed=21)
+    sc1.people = np.ascontiguousarray(sc1.people[:, :, :, :2]); sc1.N = 2
+    r_cut = oracle.evaluate(prm, sc1, sc1.init_params, jacobian=False)["residuals"]
+    rows = np.arange(r_pad.shape[1])
+    T = sc2.T
+    social = np.array([8 * t + 1 + min(max(t - 1, 0), 2) for t in range(T)])
+    others = np.setdiff1d(rows, social)
+    assert np.allclose(r_pad[:, others], r_cut[:, others], rtol=0, atol=0)
+    assert np.all(r_pad[:, social] >= r_cut[:, social]) and np.any(r_pad[:, social] > r_cut[:, social])
+
+
+def test_quirk_velocity_rows_are_zero_beyond_control_horizon(oracle):
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 2, 3, map_cells=80, seed=3)
+    ev = oracle.evaluate(prm, sc, sc.init_params)
+    CH = 18
+    for t in range(CH, sc.T):
+        row = 8 * t + 3 + 2
+        assert np.all(ev["residuals"][:, row] == 0.0) and np.all(ev["jacobian"][:, row, :] == 0.0)
+
+
+def test_no_people_problem_has_5T_rows(oracle):
+    prm = OptimizerParams.params_yaml().replace(control_horizon=18, linear_solver_type="DENSE_QR")
+    assert prm.dims(38, False) == (18, 4, 5, 10, 5 * 38 + 3, 4)       # cfg1: P=10, M=193
+    assert OptimizerParams.params_yaml().dims(38, False)[4] == 194     # unmodified file
+    sc = make_scenes(prm, 3, 3, map_cells=80, seed=4, people_present=False)
+    ev = oracle.evaluate(prm, sc, sc.init_params)
+    assert np.all(ev["residuals"][:, 193:] == 0.0)
+    res = oracle.solve(prm, sc)
+    assert np.all(res["status"] != 2)
+
+
+def test_dense_qr_and_dense_schur_give_the_same_step_sequence(oracle):
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 8, 4, map_cells=80, seed=33, standing_fraction=0.0)
+    a = oracle.solve(prm, sc)
+    b = oracle.solve(prm.replace(linear_solver_type="DENSE_QR"), sc)
+    c = oracle.solve(prm.replace(linear_solver_type="DENSE_NORMAL_CHOLESKY"), sc)
+    assert np.max(cmd_err(a["cmds"], b["cmds"])) < 1e-7
+    assert np.max(cmd_err(a["cmds"], c["cmds"])) < 1e-7
