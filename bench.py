@@ -21,6 +21,24 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def usable_cores():
+    """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def algorithmic_bytes_per_sweep(N, T, P, M):
     """every input read once, J and r written once, per scene per sweep."""
     return 8 * (6 * N * T + 2 * (T + 1) + P + 5) + 16 * T + 8 * (M * P + M)
@@ -134,19 +152,25 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py as O
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             n_sample = min(B, 32 * cores)
             sample = scenes.select(np.arange(n_sample))
             t1 = time.perf_counter()
-            ref = O.solve(prm, sample, nthreads=cores)
+            ref = O.solve(prm, sample, nthreads=cores)          # reference-literal oracle: the timed CPU baseline
             cpu_s = time.perf_counter() - t1
+            refz = O.solve(prm, sample, nthreads=cores, theta_zero_convention=True)   # checker
             got = out["cmds"][:n_sample].cpu().numpy()
-            dcmd = np.abs(got - ref["cmds"]).reshape(n_sample, -1).max(axis=1)
+            dcmd = np.abs(got - refz["cmds"]).reshape(n_sample, -1).max(axis=1)
+            clean = ref["sign_noise_events"] == 0
+            dlit = np.abs(got - ref["cmds"]).reshape(n_sample, -1).max(axis=1)
             line["cpu_baseline"] = {"value": n_sample / cpu_s, "unit": "solves/s", "cores": cores, "kind": "port",
                                     "sample": f"first {n_sample} scenes of the same workload, one solve per thread "
                                               f"(CPU restatement oracle/smpc_oracle.cpp, not Ceres), {cpu_s:.1f} s"}
             line["parity"] = {"scenes": int(n_sample), "max_abs_dcmd": float(dcmd.max()),
-                              "median_abs_dcmd": float(np.median(dcmd)), "scenes_over_1e-5": int((dcmd > 1e-5).sum())}
+                              "median_abs_dcmd": float(np.median(dcmd)), "scenes_over_1e-5": int((dcmd > 1e-5).sum()),
+                              "checker": "CPU oracle, theta:=0 convention for exactly equal velocities",
+                              "literal_oracle": {"scenes_without_sign_noise": int(clean.sum()),
+                                                 "max_abs_dcmd_on_those": float(dlit[clean].max()) if clean.any() else None}}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -1,18 +1,18 @@
-// smpc_device.hpp — gfx950 device code of the batched social-MPC solver (one 64-lane wavefront per scene).
+// smpc_device.hpp — gfx950 device code of the batched social-MPC solver: the residual/Jacobian sweep (K1).
 //
 // What this restates, MI355X-first (reference files relative to /root/reference):
 //   * rollout a1 (include/nav2_social_mpc_controller/update_state.hpp:37-63) as ONE shared rollout per sweep
-//     plus closed-form sensitivities S_t = d(x,y,theta)_{t+1}/d(params) instead of the reference's per-functor
+//     plus closed-form sensitivities S_t = d(x,y,theta)_{t+1}/d(params), instead of the reference's per-functor
 //     O(t) re-integration on ceres::Jet;
 //   * the nine instantiated residual kinds a2..a9 (include/.../critics/*_cost_function.hpp) with analytic
 //     state-space gradients (x, y, theta, v_block) chained with S_t — equal to Ceres autodiff in exact arithmetic;
-//   * Gram contraction [J r]^T [J r] (gives J^T J, J^T r and the cost);
-//   * the Ceres trust-region LM loop a11 and the post-solve unpack a12
-//     (src/optimizer.cpp:390-446).
+//   * the Gram contraction [J r]^T [J r] (gives J^T J, J^T r and the cost in one pass).
 //
-// Lane mapping of the sweep ("pair rounds"): the T*N (step, agent) social-force pairs are dealt to lanes in
-// rounds of floor(64/N) whole steps; lane t (< T) then owns horizon step t for every per-step critic; the
-// horizon pose block lives in LDS; per-step sums over agents go through LDS in a fixed order (deterministic).
+// Lane mapping: a 64-lane wavefront is split into S = 64/W "slots" of W lanes (W = 32 when T+1 <= 32, else 64);
+// each slot works on its own scene, lane `sl` of a slot owns horizon step t = sl (pose after t+1 steps) for every
+// critic, and walks the N agents of that step in a register-resident loop (no cross-lane traffic for the social
+// terms). The horizon's cos/sin block and the staged people block live in LDS; per-step reductions over the slot
+// use wavefront shuffles.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,7 +23,7 @@
 namespace smpc {
 
 constexpr int kWave = 64;
-constexpr int kPairOut = 15;  // F(2) dF/d{x,y,th,v}(8) |F|^2(1) d|F|^2(4)
+constexpr int kSoc = 15;  // sum F(2), sum dF/d{x,y,th,v}(8), sum |G|^2 (1), sum d|G|^2/d{x,y,th,v} (4)
 
 struct KParams {
   int B, T, N, CH, bl, nb, P, nbounded, nfeas;
@@ -48,6 +48,7 @@ struct KParams {
   int32_t* o_evaluations;
   double* o_initial_cost;
   double* o_final_cost;
+  int* queue;  // scene work queue (one int, zeroed before every solve launch)
   // eval (K1) inputs / outputs
   const double* e_x;
   double* e_residuals;
@@ -57,36 +58,47 @@ struct KParams {
   int e_M;  // row stride of the eval outputs (M with people)
 };
 
-// LDS carve-up (in doubles) for one wave. Everything a sweep shares across lanes lives here.
+// LDS carve-up (in doubles) of ONE slot.
 struct LdsLayout {
-  int ag;       // [5][T*N]   px, py, wx, wy, valid
-  int pose;     // [5][T+1]   x, y, theta, cos, sin  (index k = pose after k steps)
-  int pair;     // [15][64]
-  int lm;       // LM vectors / matrices
+  int ag;       // [4][N][T]  px, py, wx, wy of people_proj[t+1]
+  int valid;    // [T]        bit a set = agent a valid at step t (64-bit words)
+  int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
+  int lm;       // LM vectors / matrices / scalars
+  int gram;     // [(P+1)^2] Gram of the latest sweep (VALU back-end; the MFMA back-end uses the wave's result tile)
   int scratch;  // polynomial scratch
   int total;
 };
 
-__host__ __device__ inline LdsLayout make_layout(int T, int N, int P) {
+__host__ __device__ inline LdsLayout make_layout(int T, int N, int P, bool with_lm) {
   LdsLayout L;
   int o = 0;
-  L.ag = o; o += 5 * T * (N > 0 ? N : 1);
-  L.pose = o; o += 5 * (T + 1);
-  L.pair = o; o += kPairOut * kWave;
-  L.lm = o; o += 12 * P + 2 * P * P + 8;
-  L.scratch = o; o += 96;
-  L.total = o;
+  L.ag = o; o += 4 * T * (N > 0 ? N : 1);
+  L.valid = o; o += T;
+  L.cs = o; o += 2 * (T + 1);
+  L.lm = o; if (with_lm) o += P * P + 6 * P + 24;
+  L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
+  L.scratch = o; if (with_lm) o += 96;
+  L.total = (o + 1) & ~1;
   return L;
 }
 
-__device__ inline int lane_id() { return threadIdx.x & 63; }
+__host__ __device__ inline int slot_width(int T, int N) { return (T + 1 <= 32 && N <= 32) ? 32 : 64; }
 
-__device__ inline double wave_sum(double v) {
+// Gram contraction back-end: MFMA f64 16x16x4 when [J r] (P+1 columns) of every slot of the wave fits the 16
+// columns of one tile (two 32-lane slots -> 8 columns each), else plain VALU accumulation + shuffle reduction.
+__host__ __device__ constexpr bool use_mfma(int P, int W) { return (W == 32) ? (P + 1 <= 8) : (P + 1 <= 16); }
+__host__ __device__ constexpr int tile_cols(int W) { return (W == 32) ? 8 : 16; }
+__host__ __device__ constexpr int tile_slot_stride(int W) { return W * tile_cols(W) + ((W == 32) ? 16 : 0); }  // +32 dwords: bank shift
+// doubles of wave-shared LDS behind the per-slot blocks: row tile + 16x16 result tile
+__host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
+  return use_mfma(P, W) ? (kWave / W) * tile_slot_stride(W) + 256 : 0;
+}
+
+template <int W> __device__ inline double slot_sum(double v) {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  for (int off = W / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ inline int wave_any(int pred) { return __any(pred); }
 
 __device__ inline double wrap_to_pi(double a) {  // critics/social_work_cost_function.hpp:39-46
   while (a > M_PI) a -= 2.0 * M_PI;
@@ -94,57 +106,68 @@ __device__ inline double wrap_to_pi(double a) {  // critics/social_work_cost_fun
   return a;
 }
 
+// atan2(sin u, cos u) restated as a range reduction of u into (-pi, pi]; equal up to round-off
+// (critics/agent_angle_cost_function.hpp:156, critics/goal_align_cost_function.hpp:111-112).
+__device__ inline double wrap_angle(double u) {
+  const double k = rint(u * (0.5 / M_PI));
+  double r = fma(-k, 2.0 * M_PI, u);
+  r = fma(-k, 2.4492935982947064e-16, r);  // 2*pi - (double)(2*pi)
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------------
-// Social force between one (me, other) pair and its Jacobians with respect to diff = me_pos - other_pos and
+// Social force between one (me, other) pair and its derivatives with respect to diff = me_pos - other_pos and
 // u = me_vel - other_vel. Restates computeSocialForce (critics/social_work_cost_function.hpp:164-228) for a
-// single "other"; constants from src/critics/social_work_cost_function.cpp:38-43.
-// F = k (fv i + fa i_perp). Outputs F and the four directional derivatives along
-//   d/d(diff_x), d/d(diff_y), d/d(u_x), d/d(u_y).
+// single "other"; constants from src/critics/social_work_cost_function.cpp:38-43. F = k (fv i + fa i_perp).
 // ------------------------------------------------------------------------------------------------
 struct Force {
   double fx, fy;
-  double dfx_dx, dfy_dx, dfx_dy, dfy_dy;    // wrt diff
+  double dfx_dx, dfy_dx, dfx_dy, dfy_dy;      // wrt diff
   double dfx_dux, dfy_dux, dfx_duy, dfy_duy;  // wrt u
 };
 
 __device__ inline Force social_force(double dx, double dy, double ux, double uy) {
   const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, nn = 2.0, k = 2.1;
   Force R;
-  double n2 = dx * dx + dy * dy;
-  double n = sqrt(n2);
-  bool degenerate = n < 1e-6;  // :181-184  diff := (1e-6, 0), a constant: no dependence on positions
-  if (degenerate) { dx = 1e-6; dy = 0.0; n = sqrt(dx * dx + dy * dy); }
+  double n = sqrt(dx * dx + dy * dy);
+  const bool degenerate = n < 1e-6;  // :181-184  diff := (1e-6, 0), a constant: no dependence on positions
+  if (degenerate) { dx = 1e-6; dy = 0.0; n = 1e-6; }
   const double inv_n = 1.0 / n;
-  const double ex = dx * inv_n, ey = dy * inv_n;  // diffDirection
-  const double ivx = lambda * ux + ex, ivy = lambda * uy + ey;  // :191-192
-  const double L = sqrt(ivx * ivx + ivy * ivy);                 // :194
+  const double ex = dx * inv_n, ey = dy * inv_n;  // diffDirection :185
+  const double lux = lambda * ux, luy = lambda * uy;
+  const double ivx = lux + ex, ivy = luy + ey;  // :191-192
+  const double L = sqrt(ivx * ivx + ivy * ivy);  // :194
   const double inv_L = 1.0 / L;
-  const double ix = ivx * inv_L, iy = ivy * inv_L;              // :195-196
-  const double phi = wrap_to_pi(atan2(ey, ex) - atan2(iy, ix));  // :198-200
-  const double Bq = gamma * L;                                  // :203
+  const double ix = ivx * inv_L, iy = ivy * inv_L;  // :195-196
+  // Equal velocities (robot stopped beside a standing person): theta is mathematically 0 and the reference's
+  // value is 0 up to the last-bit noise of its own libm (which then decides sign(theta), :210). Take exactly 0.
+  const double phi = (lux == 0.0 && luy == 0.0) ? 0.0 : wrap_to_pi(atan2(ey, ex) - atan2(iy, ix));  // :198-200
+  const double Bq = gamma * L;  // :203
   const double inv_B = 1.0 / Bq;
   const double a1 = nPrime * Bq * phi, a2 = nn * Bq * phi;
   const double base = -n * inv_B;
-  const double E1 = exp(base - a1 * a1);                        // :205-207
-  const double E2 = exp(base - a2 * a2);                        // :212-215
-  const double sgn = (phi > 0.0) ? 1.0 : -1.0;                  // :210
+  const double E1 = exp(base - a1 * a1);  // :205-207
+  const double E2 = exp(base - a2 * a2);  // :212-215
+  const double sgn = (phi > 0.0) ? 1.0 : -1.0;  // :210
   const double fv = -E1, fa = -sgn * E2;
-  // F = k (fv i + fa i_perp), i_perp = (-iy, ix)                  :218-224
-  R.fx = k * (fv * ix - fa * iy);
+  R.fx = k * (fv * ix - fa * iy);  // :218-224, i_perp = (-iy, ix)
   R.fy = k * (fv * iy + fa * ix);
-
-  // directional derivative along a direction that moves: n by dn, alpha=atan2(e) by dalpha, iv by (divx, divy)
+  // Directional derivative along a direction that moves n by dn, alpha = atan2(e) by dalpha, iv by (divx, divy):
+  //   dL = i . div,  kappa = d atan2(i) = (i_perp . div) / L,  dphi = dalpha - kappa,  dB = gamma dL,
+  //   d(arg_m) = -dn/B + n dB/B^2 - 2 a_m c_m (dB phi + B dphi),
+  //   dF = k ((dfv - fa kappa) i + (dfa + fv kappa) i_perp).
+  const double nB2 = n * inv_B * inv_B;
   auto dirderiv = [&](double dn, double dalpha, double divx, double divy, double& ofx, double& ofy) {
     const double dL = ix * divx + iy * divy;
-    const double kappa = (-iy * divx + ix * divy) * inv_L;  // d beta = d atan2(i)
+    const double kappa = (ix * divy - iy * divx) * inv_L;
     const double dphi = dalpha - kappa;
     const double dB = gamma * dL;
-    const double dbase = -dn * inv_B + n * dB * inv_B * inv_B;
-    const double darg1 = dbase - 2.0 * a1 * nPrime * (dB * phi + Bq * dphi);
-    const double darg2 = dbase - 2.0 * a2 * nn * (dB * phi + Bq * dphi);
+    const double dbase = nB2 * dB - dn * inv_B;
+    const double common = dB * phi + Bq * dphi;
+    const double darg1 = dbase - 2.0 * a1 * nPrime * common;
+    const double darg2 = dbase - 2.0 * a2 * nn * common;
     const double dfv = -E1 * darg1;
     const double dfa = -sgn * E2 * darg2;
-    // dF = k ((dfv - fa kappa) i + (dfa + fv kappa) i_perp)
     const double ci = dfv - fa * kappa, cp = dfa + fv * kappa;
     ofx = k * (ci * ix - cp * iy);
     ofy = k * (ci * iy + cp * ix);
@@ -198,29 +221,24 @@ __device__ inline void bicubic(const uint8_t* __restrict__ map, int size_x, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-wave scene context
+// Per-slot scene context (registers; slot-uniform unless noted)
 // ------------------------------------------------------------------------------------------------
-template <int NB>
 struct Ctx {
-  static constexpr int P = 2 * NB;
   const KParams* kp;
-  int scene;
-  int lane;
+  int scene;   // scene index of this slot
+  int sl;      // lane within the slot = horizon step owned by this lane (per-lane)
   bool has_people;
   double x0, y0, yaw0, goal_yaw, ox, oy;
   const uint8_t* map;
-  const double* path_pts;  // [T+1][2]
-  double* lds;
+  double* lds;  // this slot's LDS block
+  double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
+  int slot;
   LdsLayout L;
-  // per-lane (lane t owns step t): agent-angle tag (a7) and path targets
+  // per-lane: agent-angle tag (a7) and path targets of step sl
   bool aa_active;
   double aa_target;
-  double tx, ty;    // path_pts[t+1]
-  double gx, gy;    // final trajectorized point
-  // pair slot of this lane within a round
-  int spr;      // steps per round
-  int pj, pa;   // step-in-round, agent index
-  bool pslot;   // lane holds a pair slot
+  double tx, ty;  // path_pts[sl+1]
+  double gx, gy;  // final trajectorized point
 };
 
 // Gram matrix [J r]^T [J r], packed upper triangle over P+1 columns (column P is r).
@@ -245,339 +263,407 @@ template <int P> struct Gram {
   __device__ inline double H(int a, int b) const { return a <= b ? v[idx(a, b)] : v[idx(b, a)]; }
 };
 
-// One-time per-scene setup: stage people into LDS (px, py, wx, wy, valid), agent-angle tags, path targets.
-template <int NB>
-__device__ inline void setup_scene(Ctx<NB>& c) {
+// Dense symmetric view of the slot's Gram [J r]^T [J r] left in LDS by sweep(): G(a, b), a, b in 0..P (column P = r).
+struct GramView {
+  const double* base;
+  int ld;
+  __device__ inline double operator()(int a, int b) const { return base[a * ld + b]; }
+};
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// Load the slot's scene constants and stage its people block into LDS (px, py, wx, wy per (agent, step); valid
+// mask per step), compute the agent-angle tags. Executed by all W lanes of the slot (other slots may be masked off).
+template <int W>
+__device__ inline void load_scene(Ctx& c, int scene) {
   const KParams& k = *c.kp;
-  const int T = k.T, N = k.N, lane = c.lane;
-  double* ag = c.lds + c.L.ag;
-  const int TN = T * N;
-  if (c.has_people) {
-    const double* ppl = k.people + (size_t)c.scene * (T + 1) * 6 * N;
-    for (int q = lane; q < TN; q += kWave) {
-      const int t = q / N, a = q - t * N;
-      const double* f = ppl + (size_t)(t + 1) * 6 * N + a;  // people_proj[t + 1]
-      const double px = f[0], py = f[N], yaw = f[2 * N], tt = f[3 * N], lv = f[4 * N];
-      double sn, cs;
-      sincos(yaw, &sn, &cs);
-      ag[0 * TN + q] = px;
-      ag[1 * TN + q] = py;
-      ag[2 * TN + q] = lv * cs;   // aVel, social_work:187-188
-      ag[3 * TN + q] = lv * sn;
-      ag[4 * TN + q] = (tt == -1.0) ? 0.0 : 1.0;  // :175
-    }
-  }
-  // a7 AgentAngle tag: depends on constants only (critics/agent_angle_cost_function.hpp:130-190)
+  const int T = k.T, N = k.N, sl = c.sl;
+  const size_t s = scene;
+  c.scene = scene;
+  c.has_people = (N > 0) && (k.has_people ? k.has_people[s] != 0 : true);
+  c.x0 = k.pose0[3 * s];
+  c.y0 = k.pose0[3 * s + 1];
+  c.yaw0 = k.pose0[3 * s + 2];
+  c.goal_yaw = k.goal_yaw[s];
+  const size_t cm = (size_t)k.size_x * k.size_y;
+  c.map = k.costmap + (k.costmap_shared ? 0 : cm * s);
+  c.ox = k.costmap_origin[k.costmap_shared ? 0 : 2 * s];
+  c.oy = k.costmap_origin[k.costmap_shared ? 1 : 2 * s + 1];
+  const double* path_pts = k.path_pts + s * (T + 1) * 2;
+  const int tl = min(sl, T - 1);
+  c.tx = path_pts[2 * (tl + 1)];
+  c.ty = path_pts[2 * (tl + 1) + 1];
+  c.gx = path_pts[2 * T];
+  c.gy = path_pts[2 * T + 1];
   c.aa_active = false;
   c.aa_target = 0.0;
-  if (c.has_people && lane < T) {
-    const double* ppl = k.people + (size_t)c.scene * (T + 1) * 6 * N + (size_t)(lane + 1) * 6 * N;
-    int closest = -1;
-    double best = INFINITY;
-    for (int a = 0; a < N; ++a) {
-      const double ddx = ppl[a] - c.x0, ddy = ppl[N + a] - c.y0;
-      const double d2 = ddx * ddx + ddy * ddy;
-      if (d2 < best && ppl[4 * N + a] > 0.05) { best = d2; closest = a; }
+  if (c.has_people) {
+    double* ag = c.lds + c.L.ag;
+    unsigned long long* vmask = reinterpret_cast<unsigned long long*>(c.lds + c.L.valid);
+    const double* ppl = k.people + s * (size_t)(T + 1) * 6 * N;
+    const int TN = T * N;
+    // element q = a*T + t of each component plane; people_proj[t+1] field f agent a is at ((t+1)*6 + f)*N + a
+    for (int q = sl; q < TN; q += W) {
+      const int a = q / T, t = q - a * T;
+      const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
+      const double px = f[0], py = f[N], yaw = f[2 * N], lv = f[4 * N];
+      double sn, cs;
+      sincos(yaw, &sn, &cs);
+      ag[q] = px;
+      ag[TN + q] = py;
+      ag[2 * TN + q] = lv * cs;  // aVel, social_work:187-188
+      ag[3 * TN + q] = lv * sn;
     }
-    if (closest >= 0 && !(best > 4.0)) {
-      const double ax = ppl[closest], ay = ppl[N + closest], ayaw = ppl[2 * N + closest];
-      const double agent_angle_initial = atan2(ay - c.y0, ax - c.x0);
-      const double hd = ayaw - c.yaw0;
-      const double heading_diff = atan2(sin(hd), cos(hd));
-      const double rel0 = agent_angle_initial - c.yaw0;
-      const double rel = atan2(sin(rel0), cos(rel0));
-      const double kThr = M_PI / 6.0, kUp = 5 * M_PI / 6.0;
-      if (heading_diff <= -kUp || heading_diff >= kThr) {
-        if (!(rel < 0.0)) { c.aa_active = true; c.aa_target = c.yaw0 + (-(M_PI / 6.0)); }
-      } else {
-        if (!(rel > 0.0)) { c.aa_active = true; c.aa_target = c.yaw0 + (M_PI / 6.0); }
+    if (sl < T) {
+      const double* f = ppl + (size_t)(sl + 1) * 6 * N;
+      unsigned long long m = 0;
+      // a7 AgentAngle tag: depends on constants only (critics/agent_angle_cost_function.hpp:130-190)
+      int closest = -1;
+      double best = INFINITY;
+      for (int a = 0; a < N; ++a) {
+        if (f[3 * N + a] != -1.0) m |= (1ull << a);  // social_work:175
+        const double ddx = f[a] - c.x0, ddy = f[N + a] - c.y0;
+        const double d2 = ddx * ddx + ddy * ddy;
+        if (d2 < best && f[4 * N + a] > 0.05) { best = d2; closest = a; }
+      }
+      vmask[sl] = m;
+      if (closest >= 0 && !(best > 4.0)) {
+        const double ax = f[closest], ay = f[N + closest], ayaw = f[2 * N + closest];
+        const double agent_angle_initial = atan2(ay - c.y0, ax - c.x0);
+        const double hd = ayaw - c.yaw0;
+        const double heading_diff = atan2(sin(hd), cos(hd));
+        const double rel0 = agent_angle_initial - c.yaw0;
+        const double rel = atan2(sin(rel0), cos(rel0));
+        const double kThr = M_PI / 6.0, kUp = 5 * M_PI / 6.0;
+        if (heading_diff <= -kUp || heading_diff >= kThr) {
+          if (!(rel < 0.0)) { c.aa_active = true; c.aa_target = c.yaw0 + (-(M_PI / 6.0)); }
+        } else {
+          if (!(rel > 0.0)) { c.aa_active = true; c.aa_target = c.yaw0 + (M_PI / 6.0); }
+        }
       }
     }
   }
-  c.tx = c.ty = 0.0;
-  if (lane < T) { c.tx = c.path_pts[2 * (lane + 1)]; c.ty = c.path_pts[2 * (lane + 1) + 1]; }
-  c.gx = c.path_pts[2 * T];
-  c.gy = c.path_pts[2 * T + 1];
-  c.spr = (N > 0) ? kWave / N : 0;
-  c.pj = (N > 0) ? lane / N : 0;
-  c.pa = (N > 0) ? lane - c.pj * N : 0;
-  c.pslot = (N > 0) && (c.pj < c.spr);
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
-// The sweep (kernel K1's body): residuals + Jacobian rows + Gram at parameters x[P] (uniform across lanes).
-// Returns the Gram in all lanes; `finite` is false if any residual / Jacobian entry is non-finite.
+// The sweep (kernel K1's body): residuals + Jacobian rows + Gram at the slot's parameters xp[P] (LDS or global,
+// slot-uniform). All 64 lanes of the wave call it together (each slot on its own scene). The Gram is returned
+// reduced over the slot in every lane of the slot.
 // When out_r / out_J are non-null (stand-alone K1) the rows are also written to HBM in the reference order.
 // ------------------------------------------------------------------------------------------------
-template <int NB>
-__device__ inline void sweep(Ctx<NB>& c, const double (&x)[2 * NB], Gram<2 * NB>& gram, bool& finite,
-                             double* out_r, double* out_J) {
+template <int NB, int W>
+__device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J) {
   constexpr int P = 2 * NB;
   const KParams& k = *c.kp;
-  const int T = k.T, N = k.N, CH = k.CH, bl = k.bl, lane = c.lane;
+  const int T = k.T, N = k.N, CH = k.CH, bl = k.bl, sl = c.sl;
   const double dt = k.dt;
-  double* pose = c.lds + c.L.pose;
-  double* px_ = pose, *py_ = pose + (T + 1), *pth_ = pose + 2 * (T + 1), *pc_ = pose + 3 * (T + 1), *ps_ = pose + 4 * (T + 1);
+  double* cs_ = c.lds + c.L.cs;
+  double* sn_ = cs_ + (T + 1);
   const int blast = (CH - 1) / bl;
-
-  // ---- a1 rollout. theta_j: sequential adds in the reference's order; lane j holds theta_j (j = 0..T).
-  double th = c.yaw0;
-  for (int j = 0; j < T; ++j) {
-    const int b = (j < CH) ? j / bl : blast;
-    double w = 0.0;
+  double x[P];
 #pragma unroll
-    for (int q = 0; q < NB; ++q) w = (q == b) ? x[2 * q + 1] : w;
-    if (j < lane) th += w * dt;
+  for (int q = 0; q < P; ++q) x[q] = xp[q];
+
+  // ---- a1 rollout, block-structured. theta_sl by sequential adds in the reference's order (:46-61).
+  double th = c.yaw0;
+  {
+    int j = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int end = (b >= blast) ? ((b == blast) ? T : 0) : (b + 1) * bl;
+      const double wdt = x[2 * b + 1] * dt;
+      for (; j < end; ++j) th += (j < sl) ? wdt : 0.0;
+    }
   }
+  const int myb = (sl < CH) ? sl / bl : blast;  // block driving step sl
+  double vb = 0.0, wb = 0.0;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) { vb = (q == myb) ? x[2 * q] : vb; wb = (q == myb) ? x[2 * q + 1] : wb; }
   double sn, cs;
   sincos(th, &sn, &cs);
-  if (lane <= T) { pth_[lane] = th; pc_[lane] = cs; ps_[lane] = sn; }
+  if (sl <= T) { cs_[sl] = cs; sn_[sl] = sn; }
+  const double th1 = th + wb * dt;  // theta_{sl+1}: the same add the reference performs at step sl
   __syncthreads();
-  // x, y and sensitivities of pose_{lane+1}: sequential sums over j = 0..lane (reference summation order).
+  // x, y of pose_{sl+1} (sequential sums over j <= sl) and the sensitivities S of that pose.
   double X = c.x0, Y = c.y0;
   double Sxv[NB], Syv[NB], Sxw[NB], Syw[NB], Sthw[NB];
+  {
+    int j = 0;
 #pragma unroll
-  for (int q = 0; q < NB; ++q) Sxv[q] = Syv[q] = Sxw[q] = Syw[q] = Sthw[q] = 0.0;
-  for (int j = 0; j < T; ++j) {
-    const int b = (j < CH) ? j / bl : blast;
-    const double cj = pc_[j], sj = ps_[j];
-    double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) v = (q == b) ? x[2 * q] : v;
-    if (j <= lane) {
-      X += v * cj * dt;
-      Y += v * sj * dt;
-      // d x_{j+1} += dt (dv cos - v sin dtheta_j); dtheta_j/dw_q = Sthw[q] (before this step's increment)
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        Sxw[q] = fma(-v * sj * dt, Sthw[q], Sxw[q]);
-        Syw[q] = fma(v * cj * dt, Sthw[q], Syw[q]);
-        if (q == b) { Sxv[q] += cj * dt; Syv[q] += sj * dt; Sthw[q] += dt; }
+    for (int b = 0; b < NB; ++b) {
+      const int start = b * bl;
+      const int end = (b >= blast) ? ((b == blast) ? T : 0) : (b + 1) * bl;
+      const double v = x[2 * b];
+      const double vdt = v * dt;
+      double aC = 0.0, aS = 0.0, aJC = 0.0, aJS = 0.0;
+      for (; j < end; ++j) {
+        const double cj = cs_[j], sj = sn_[j];
+        const bool on = j <= sl;
+        const double kk = (double)(j - start);
+        X += on ? v * cj * dt : 0.0;
+        Y += on ? v * sj * dt : 0.0;
+        aC += on ? cj : 0.0;
+        aS += on ? sj : 0.0;
+        aJC = on ? fma(kk, cj, aJC) : aJC;
+        aJS = on ? fma(kk, sj, aJS) : aJS;
       }
+      Sxv[b] = dt * aC;
+      Syv[b] = dt * aS;
+      // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
+      Sxw[b] = -vdt * dt * aJS;
+      Syw[b] = vdt * dt * aJC;
+#pragma unroll
+      for (int q = 0; q < b; ++q) {
+        Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
+        Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
+      }
+      const int cnt = min(max(sl + 1 - start, 0), end - start);
+      Sthw[b] = dt * (double)max(cnt, 0);
     }
   }
-  if (lane < T) { px_[lane + 1] = X; py_[lane + 1] = Y; }
-  __syncthreads();
-  const int myb = (lane < CH) ? lane / bl : blast;  // block driving step `lane`
-  double vb = 0.0;
-#pragma unroll
-  for (int q = 0; q < NB; ++q) vb = (q == myb) ? x[2 * q] : vb;
-  // cos/sin of theta_{lane+1} (robot heading at the residual's pose)
-  const double c1 = (lane < T) ? pc_[lane + 1] : 1.0, s1 = (lane < T) ? ps_[lane + 1] : 0.0;
-  const double th1 = (lane < T) ? pth_[lane + 1] : 0.0;
+  const int t1 = min(sl + 1, T);
+  const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
 
-  // ---- a3 social-work pair rounds
-  double soc[kPairOut];
+  // ---- a3 social work + a4 proxemics: walk the agents of step sl
+  double soc[kSoc];
 #pragma unroll
-  for (int i = 0; i < kPairOut; ++i) soc[i] = 0.0;
+  for (int i = 0; i < kSoc; ++i) soc[i] = 0.0;
+  double pbest = 1.7976931348623157e308, pdx = 0.0, pdy = 0.0;
   if (c.has_people) {
-    double* pair = c.lds + c.L.pair;
     const double* ag = c.lds + c.L.ag;
+    const unsigned long long* vmask = reinterpret_cast<const unsigned long long*>(c.lds + c.L.valid);
     const int TN = T * N;
-    const int rounds = (T + c.spr - 1) / c.spr;
-    for (int r = 0; r < rounds; ++r) {
-      const int t = r * c.spr + c.pj;
-      double o[kPairOut];
-#pragma unroll
-      for (int i = 0; i < kPairOut; ++i) o[i] = 0.0;
-      if (c.pslot && t < T) {
-        const int q = t * N + c.pa;
-        const double apx = ag[q], apy = ag[TN + q], awx = ag[2 * TN + q], awy = ag[3 * TN + q];
-        const bool valid = ag[4 * TN + q] != 0.0;
-        const double rx = px_[t + 1], ry = py_[t + 1], rc = pc_[t + 1], rs = ps_[t + 1];
-        const int tb = (t < CH) ? t / bl : blast;
-        double rv = 0.0;
-#pragma unroll
-        for (int qq = 0; qq < NB; ++qq) rv = (qq == tb) ? x[2 * qq] : rv;
-        const double rvx = rv * rc, rvy = rv * rs;  // meVel, social_work:170-171
-        const double dx = rx - apx, dy = ry - apy;
-        const bool degenerate = (dx * dx + dy * dy) < 1e-12;  // sqrt(n2) < 1e-6
-        if (valid) {
-          // force on the robot from this agent (:125): diff = robot - agent, u = robotVel - agentVel
-          const Force F = social_force(dx, dy, rvx - awx, rvy - awy);
-          const double dFx_dth = rv * (-rs * F.dfx_dux + rc * F.dfx_duy), dFy_dth = rv * (-rs * F.dfy_dux + rc * F.dfy_duy);
-          const double dFx_dv = rc * F.dfx_dux + rs * F.dfx_duy, dFy_dv = rc * F.dfy_dux + rs * F.dfy_duy;
-          o[0] = F.fx; o[1] = F.fy;
-          o[2] = F.dfx_dx; o[3] = F.dfy_dx; o[4] = F.dfx_dy; o[5] = F.dfy_dy;
-          o[6] = dFx_dth; o[7] = dFy_dth; o[8] = dFx_dv; o[9] = dFy_dv;
-          if (!degenerate) {
-            // force on the agent from the robot (:137-143) is exactly -F for a non-degenerate pair
-            o[10] = F.fx * F.fx + F.fy * F.fy;
-            o[11] = 2.0 * (F.fx * F.dfx_dx + F.fy * F.dfy_dx);
-            o[12] = 2.0 * (F.fx * F.dfx_dy + F.fy * F.dfy_dy);
-            o[13] = 2.0 * (F.fx * dFx_dth + F.fy * dFy_dth);
-            o[14] = 2.0 * (F.fx * dFx_dv + F.fy * dFy_dv);
-          }
-        }
-        if (!valid || degenerate) {
-          // phantom / degenerate: force on the agent from the robot evaluated on its own
-          // (diff = agent - robot, u = agentVel - robotVel), derivative signs flip through diff and u.
-          const Force G = social_force(-dx, -dy, awx - rvx, awy - rvy);
-          const double gx_x = -G.dfx_dx, gy_x = -G.dfy_dx, gx_y = -G.dfx_dy, gy_y = -G.dfy_dy;
-          const double gx_th = -rv * (-rs * G.dfx_dux + rc * G.dfx_duy), gy_th = -rv * (-rs * G.dfy_dux + rc * G.dfy_duy);
-          const double gx_v = -(rc * G.dfx_dux + rs * G.dfx_duy), gy_v = -(rc * G.dfy_dux + rs * G.dfy_duy);
-          o[10] = G.fx * G.fx + G.fy * G.fy;
-          o[11] = 2.0 * (G.fx * gx_x + G.fy * gy_x);
-          o[12] = 2.0 * (G.fx * gx_y + G.fy * gy_y);
-          o[13] = 2.0 * (G.fx * gx_th + G.fy * gy_th);
-          o[14] = 2.0 * (G.fx * gx_v + G.fy * gy_v);
+    const int tl = min(sl, T - 1);
+    const unsigned long long vm = vmask[tl];
+    const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
+    for (int a = 0; a < N; ++a) {
+      const int q = a * T + tl;
+      const double apx = ag[q], apy = ag[TN + q], awx = ag[2 * TN + q], awy = ag[3 * TN + q];
+      const bool valid = (vm >> a) & 1ull;
+      const double dx = X - apx, dy = Y - apy;
+      const double d2 = dx * dx + dy * dy;
+      const bool degenerate = d2 < 1e-12;  // |diff| < 1e-6
+      if (valid) {
+        if (d2 < pbest) { pbest = d2; pdx = dx; pdy = dy; }  // proxemics: first minimum wins (std::min on duals)
+        // force on the robot from this agent (:125): diff = robot - agent, u = robotVel - agentVel
+        const Force F = social_force(dx, dy, rvx - awx, rvy - awy);
+        const double dFx_dth = vb * (-s1 * F.dfx_dux + c1 * F.dfx_duy), dFy_dth = vb * (-s1 * F.dfy_dux + c1 * F.dfy_duy);
+        const double dFx_dv = c1 * F.dfx_dux + s1 * F.dfx_duy, dFy_dv = c1 * F.dfy_dux + s1 * F.dfy_duy;
+        soc[0] += F.fx; soc[1] += F.fy;
+        soc[2] += F.dfx_dx; soc[3] += F.dfy_dx; soc[4] += F.dfx_dy; soc[5] += F.dfy_dy;
+        soc[6] += dFx_dth; soc[7] += dFy_dth; soc[8] += dFx_dv; soc[9] += dFy_dv;
+        if (!degenerate) {
+          // force on the agent from the robot (:137-143) is exactly -F for a non-degenerate pair
+          soc[10] += F.fx * F.fx + F.fy * F.fy;
+          soc[11] += 2.0 * (F.fx * F.dfx_dx + F.fy * F.dfy_dx);
+          soc[12] += 2.0 * (F.fx * F.dfx_dy + F.fy * F.dfy_dy);
+          soc[13] += 2.0 * (F.fx * dFx_dth + F.fy * dFy_dth);
+          soc[14] += 2.0 * (F.fx * dFx_dv + F.fy * dFy_dv);
         }
       }
-#pragma unroll
-      for (int i = 0; i < kPairOut; ++i) pair[i * kWave + lane] = o[i];
-      __syncthreads();
-      // lanes owning the steps of this round sum their N agents in agent order
-      const int j = lane - r * c.spr;
-      if (j >= 0 && j < c.spr && lane < T) {
-        for (int a = 0; a < N; ++a) {
-#pragma unroll
-          for (int i = 0; i < kPairOut; ++i) soc[i] += pair[i * kWave + j * N + a];
-        }
+      if (!valid || degenerate) {
+        // phantom (invalid column, :137 loops every column) or coincident pair: force on the agent from the
+        // robot evaluated on its own (diff = agent - robot, u = agentVel - robotVel); signs flip through diff, u.
+        const Force G = social_force(-dx, -dy, awx - rvx, awy - rvy);
+        const double gx_th = -vb * (-s1 * G.dfx_dux + c1 * G.dfx_duy), gy_th = -vb * (-s1 * G.dfy_dux + c1 * G.dfy_duy);
+        const double gx_v = -(c1 * G.dfx_dux + s1 * G.dfx_duy), gy_v = -(c1 * G.dfy_dux + s1 * G.dfy_duy);
+        soc[10] += G.fx * G.fx + G.fy * G.fy;
+        soc[11] += -2.0 * (G.fx * G.dfx_dx + G.fy * G.dfy_dx);
+        soc[12] += -2.0 * (G.fx * G.dfx_dy + G.fy * G.dfy_dy);
+        soc[13] += 2.0 * (G.fx * gx_th + G.fy * gy_th);
+        soc[14] += 2.0 * (G.fx * gx_v + G.fy * gy_v);
       }
-      __syncthreads();
     }
   }
 
-  // ---- per-step rows (lane t < T): state-space gradients (gx, gy, gth) + direct dv on block myb
-  gram.clear();
-  finite = true;
+  // ---- per-step rows: state-space gradients (gx, gy, gth) + direct dv on block myb, pushed into the Gram
+  constexpr bool kMfma = use_mfma(P, W);
+  constexpr int kCols = tile_cols(W);
+  constexpr int Q = P + 1;
   const smpc_params& w = k.prm;
-  const int rows_per_step = c.has_people ? 8 : 5;
-  const int row0 = rows_per_step * lane + min(max(lane - 1, 0), k.nfeas) + ((lane >= 1 && lane - 1 < k.nfeas) ? 0 : 0);
-  int rowi = row0;
-  auto emit = [&](double r, double gx, double gy, double gth, double gv) {
+  const bool lane_live = sl < T;
+  const bool people = c.has_people;
+  const int rows_per_step = people ? 8 : 5;
+  const int row_base = rows_per_step * sl + min(max(sl - 1, 0), k.nfeas);
+  Gram<P> gram;        // VALU back-end accumulators (dead code in the MFMA build)
+  v4d acc = {0.0, 0.0, 0.0, 0.0};  // MFMA back-end accumulators: C[(lane>>4) + 4 reg][lane & 15]
+  double* tile = c.wave_lds;
+  double* my_row = tile + c.slot * tile_slot_stride(W) + sl * kCols;
+  const double* rd_base;
+  {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15, kq = lane >> 4;
+    rd_base = (W == 32) ? tile + (i >> 3) * tile_slot_stride(W) + kq * kCols + (i & 7) : tile + kq * kCols + i;
+  }
+  if (kMfma) {
+#pragma unroll
+    for (int q = Q; q < kCols; ++q) my_row[q] = 0.0;  // padding columns stay zero for the whole sweep
+  } else {
+    gram.clear();
+  }
+  const int n_mfma = (T + 3) / 4;
+  auto push = [&](const double (&row)[P], double r, bool live) {
+    if (kMfma) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) my_row[q] = live ? row[q] : 0.0;
+      my_row[P] = live ? r : 0.0;
+      __syncthreads();
+      for (int m = 0; m < n_mfma; ++m) {
+        const double a = rd_base[m * 4 * kCols];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    } else {
+      if (live) gram.add_row(row, r);
+    }
+  };
+  auto emit = [&](int local, bool live, double r, double gx, double gy, double gth, double gv) {
     double row[P];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       row[2 * q] = gx * Sxv[q] + gy * Syv[q] + ((q == myb) ? gv : 0.0);
       row[2 * q + 1] = gx * Sxw[q] + gy * Syw[q] + gth * Sthw[q];
     }
-    bool ok = isfinite(r);
-#pragma unroll
-    for (int q = 0; q < P; ++q) ok = ok && isfinite(row[q]);
-    if (!ok) finite = false;
-    gram.add_row(row, r);
-    if (out_r) out_r[rowi] = r;
-    if (out_J) {
-#pragma unroll
-      for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
-    }
-    ++rowi;
-  };
-  if (lane < T) {
-    if (c.has_people) {
-      // a7 agent angle
-      {
-        double r = 0.0, gth = 0.0;
-        if (c.aa_active) {
-          const double u = th1 - c.aa_target;
-          const double ad = atan2(sin(u), cos(u));
-          r = w.agent_angle_w * (ad * ad);
-          gth = w.agent_angle_w * 2.0 * ad;
-        }
-        emit(r, 0.0, 0.0, gth, 0.0);
-      }
-      // a3 social work: w (|sum F|^2 + sum |G|^2 + 1e-6)
-      {
-        const double wr = soc[0] * soc[0] + soc[1] * soc[1];
-        const double r = w.socialwork_w * (wr + soc[10] + 1e-6);
-        const double gx = w.socialwork_w * (2.0 * (soc[0] * soc[2] + soc[1] * soc[3]) + soc[11]);
-        const double gy = w.socialwork_w * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
-        const double gt = w.socialwork_w * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
-        const double gv = w.socialwork_w * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
-        emit(r, gx, gy, gt, gv);
-      }
-      // a4 proxemics: w alpha exp(-min_a d^2 / d0^2) over valid agents (first minimum wins)
-      {
-        const double* ag = c.lds + c.L.ag;
-        const int TN = T * N;
-        double best = 1.7976931348623157e308, bdx = 0.0, bdy = 0.0;
-        for (int a = 0; a < N; ++a) {
-          const int q = lane * N + a;
-          if (ag[4 * TN + q] == 0.0) continue;
-          const double ddx = X - ag[q], ddy = Y - ag[TN + q];
-          const double d2 = ddx * ddx + ddy * ddy;
-          if (d2 < best) { best = d2; bdx = ddx; bdy = ddy; }
-        }
-        const double e = 3.0 * exp(-best / (0.5 * 0.5));
-        const double r = w.proxemics_w * e;
-        const double gx = r * (-2.0 * bdx / (0.5 * 0.5)), gy = r * (-2.0 * bdy / (0.5 * 0.5));
-        emit(r, gx, gy, 0.0, 0.0);
-      }
-    }
-    // a6 velocity
-    {
-      double r = 0.0, gv = 0.0;
-      if (lane < CH) { const double d = w.desired_linear_vel - vb; r = w.velocity_w * d * d; gv = -2.0 * w.velocity_w * d; }
-      emit(r, 0.0, 0.0, 0.0, gv);
-    }
-    // a8 goal align
-    {
-      const double u = c.goal_yaw - th1;
-      const double a = atan2(sin(u), cos(u));
-      emit(w.goal_align_w * a * a, 0.0, 0.0, -2.0 * w.goal_align_w * a, 0.0);
-    }
-    // a2 distance (path follow -> final point; path align -> point t+1)
-    {
-      const double ddx = X - c.gx, ddy = Y - c.gy, q2 = ddx * ddx + ddy * ddy;
-      emit(w.distance_w * q2 * q2, 4.0 * w.distance_w * q2 * ddx, 4.0 * w.distance_w * q2 * ddy, 0.0, 0.0);
-    }
-    {
-      const double ddx = X - c.tx, ddy = Y - c.ty, q2 = ddx * ddx + ddy * ddy;
-      emit(w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
-    }
-    // a5 obstacle
-    {
-      const double fxp = X + 0.25 * c1, fyp = Y + 0.25 * s1;
-      const double inv_res = 1.0 / k.resolution;
-      const double ic = (fxp - c.ox) / k.resolution, ir = (fyp - c.oy) / k.resolution;
-      double f, dfdr, dfdc;
-      bicubic(c.map, k.size_x, k.size_y, ir, ic, f, dfdr, dfdc);
-      const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
-      const double gth = w.obstacle_w * (dfdc * (-0.25 * s1) + dfdr * (0.25 * c1)) * inv_res;
-      emit(w.obstacle_w * f, gx, gy, gth, 0.0);
-    }
-    // a9 velocity feasibility between blocks `lane` and `lane-1` (src/optimizer.cpp:364-370); row follows step `lane`
-    if (lane >= 1 && lane <= k.nfeas) {
-      double row[P];
-#pragma unroll
-      for (int q = 0; q < P; ++q) row[q] = 0.0;
-      double lin = 0.0, ang = 0.0;
-#pragma unroll
-      for (int q = 1; q < NB; ++q) {
-        if (q == lane) {
-          lin = x[2 * q] - x[2 * q - 2];
-          ang = x[2 * q + 1] - x[2 * q - 1];
-        }
-      }
-      double r = 0.0;
-      if (lane < CH) {
-        r = w.velocity_feasibility_w * lin * lin + w.velocity_feasibility_w * ang * ang;
-#pragma unroll
-        for (int q = 1; q < NB; ++q) {
-          if (q == lane) {
-            row[2 * q] = 2.0 * w.velocity_feasibility_w * lin;
-            row[2 * q - 2] = -2.0 * w.velocity_feasibility_w * lin;
-            row[2 * q + 1] = 2.0 * w.velocity_feasibility_w * ang;
-            row[2 * q - 1] = -2.0 * w.velocity_feasibility_w * ang;
-          }
-        }
-      }
-      if (!isfinite(r)) finite = false;
-      gram.add_row(row, r);
+    if (live) {
+      const int rowi = row_base + local;
       if (out_r) out_r[rowi] = r;
       if (out_J) {
 #pragma unroll
         for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
       }
-      ++rowi;
+    }
+    push(row, r, live);
+  };
+  if (__any(people)) {
+    const bool live = lane_live && people;
+    // a7 agent angle
+    {
+      double r = 0.0, gth = 0.0;
+      if (c.aa_active) {
+        const double ad = wrap_angle(th1 - c.aa_target);
+        r = w.agent_angle_w * (ad * ad);
+        gth = w.agent_angle_w * 2.0 * ad;
+      }
+      emit(0, live, r, 0.0, 0.0, gth, 0.0);
+    }
+    // a3 social work: w (|sum F|^2 + sum |G|^2 + 1e-6)
+    {
+      const double wr = soc[0] * soc[0] + soc[1] * soc[1];
+      const double r = w.socialwork_w * (wr + soc[10] + 1e-6);
+      const double gx = w.socialwork_w * (2.0 * (soc[0] * soc[2] + soc[1] * soc[3]) + soc[11]);
+      const double gy = w.socialwork_w * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
+      const double gt = w.socialwork_w * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
+      const double gv = w.socialwork_w * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
+      emit(1, live, r, gx, gy, gt, gv);
+    }
+    // a4 proxemics: w alpha exp(-min_a d^2 / d0^2) over valid agents
+    {
+      const double e = 3.0 * exp(-pbest / (0.5 * 0.5));
+      const double r = w.proxemics_w * e;
+      double gx = r * (-2.0 * pdx / (0.5 * 0.5)), gy = r * (-2.0 * pdy / (0.5 * 0.5));
+      if (pbest == 1.7976931348623157e308) {
+        // no valid agent: the reference's dual evaluation gives (-max / d0^2) = -inf and inf * 0 = NaN tangents
+        // (critics/proxemics_cost_function.hpp:127,147) -> Ceres rejects the evaluation. Mirror it.
+        gx = gy = __longlong_as_double(0x7ff8000000000000ll);
+      }
+      emit(2, live, r, gx, gy, 0.0, 0.0);
     }
   }
-  // ---- Gram reduction over lanes (all lanes end with the sums)
+  const int o5 = people ? 3 : 0;
+  // a6 velocity
+  {
+    double r = 0.0, gv = 0.0;
+    if (sl < CH) { const double d = w.desired_linear_vel - vb; r = w.velocity_w * d * d; gv = -2.0 * w.velocity_w * d; }
+    emit(o5 + 0, lane_live, r, 0.0, 0.0, 0.0, gv);
+  }
+  // a8 goal align
+  {
+    const double a = wrap_angle(c.goal_yaw - th1);
+    emit(o5 + 1, lane_live, w.goal_align_w * a * a, 0.0, 0.0, -2.0 * w.goal_align_w * a, 0.0);
+  }
+  // a2 distance (path follow -> final point; path align -> point sl+1)
+  {
+    const double ddx = X - c.gx, ddy = Y - c.gy, q2 = ddx * ddx + ddy * ddy;
+    emit(o5 + 2, lane_live, w.distance_w * q2 * q2, 4.0 * w.distance_w * q2 * ddx, 4.0 * w.distance_w * q2 * ddy, 0.0, 0.0);
+  }
+  {
+    const double ddx = X - c.tx, ddy = Y - c.ty, q2 = ddx * ddx + ddy * ddy;
+    emit(o5 + 3, lane_live, w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
+  }
+  // a5 obstacle
+  {
+    const double fxp = X + 0.25 * c1, fyp = Y + 0.25 * s1;
+    const double inv_res = 1.0 / k.resolution;
+    const double ic = (fxp - c.ox) / k.resolution, ir = (fyp - c.oy) / k.resolution;
+    double f, dfdr, dfdc;
+    bicubic(c.map, k.size_x, k.size_y, ir, ic, f, dfdr, dfdc);
+    const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
+    const double gth = w.obstacle_w * (dfdc * (-0.25 * s1) + dfdr * (0.25 * c1)) * inv_res;
+    emit(o5 + 4, lane_live, w.obstacle_w * f, gx, gy, gth, 0.0);
+  }
+  // a9 velocity feasibility between blocks sl and sl-1 (src/optimizer.cpp:364-370); the row follows step sl
+  if (k.nfeas > 0) {
+    const bool live = lane_live && sl >= 1 && sl <= k.nfeas;
+    double row[P];
 #pragma unroll
-  for (int i = 0; i < Gram<P>::SZ; ++i) gram.v[i] = wave_sum(gram.v[i]);
-  finite = !wave_any(!finite);
+    for (int q = 0; q < P; ++q) row[q] = 0.0;
+    double r = 0.0;
+#pragma unroll
+    for (int q = 1; q < NB; ++q) {
+      if (q == sl) {
+        const double lin = x[2 * q] - x[2 * q - 2], ang = x[2 * q + 1] - x[2 * q - 1];
+        r = w.velocity_feasibility_w * lin * lin + w.velocity_feasibility_w * ang * ang;
+        row[2 * q] = 2.0 * w.velocity_feasibility_w * lin;
+        row[2 * q - 2] = -2.0 * w.velocity_feasibility_w * lin;
+        row[2 * q + 1] = 2.0 * w.velocity_feasibility_w * ang;
+        row[2 * q - 1] = -2.0 * w.velocity_feasibility_w * ang;
+      }
+    }
+    if (live) {
+      const int rowi = row_base + rows_per_step;
+      if (out_r) out_r[rowi] = r;
+      if (out_J) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
+      }
+    }
+    push(row, r, live);
+  }
+  // ---- hand the slot's Gram back through LDS
+  GramView view;
+  if (kMfma) {
+    double* ctile = tile + (kWave / W) * tile_slot_stride(W);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) ctile[((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+    const int o = (W == 32) ? 8 * c.slot : 0;
+    view.base = ctile + o * 16 + o;
+    view.ld = 16;
+  } else {
+    double* gt = c.lds + c.L.gram;
+#pragma unroll
+    for (int a = 0; a < Q; ++a) {
+#pragma unroll
+      for (int b = a; b < Q; ++b) {
+        const double v = slot_sum<W>(gram.v[Gram<P>::idx(a, b)]);
+        gt[a * Q + b] = v;
+        gt[b * Q + a] = v;
+      }
+    }
+    view.base = gt;
+    view.ld = Q;
+  }
+  __syncthreads();  // Gram visible to every lane of the slot; the cos/sin block may be rewritten by the next sweep
+  return view;
+}
+
+// A sweep result is usable iff every residual and Jacobian entry was finite: a non-finite entry makes the
+// corresponding diagonal entry of the Gram (a sum of squares) non-finite.
+template <int P> __device__ inline bool gram_finite(const GramView& g) {
+  bool ok = true;
+#pragma unroll
+  for (int q = 0; q <= P; ++q) ok = ok && isfinite(g(q, q));
+  return ok;
 }
 
 }  // namespace smpc

@@ -1,9 +1,10 @@
 // smpc_hip.hip — kernels + the C ABI of include/smpc.h (libsmpc_hip.so). gfx950 only, no CPU fallback.
 //
-// Kernels (one 64-lane wavefront = one workgroup = one scene):
-//   smpc_solve_kernel<NB>  whole ceres::Solve-equivalent (reference src/optimizer.cpp:241-446) per scene,
-//                          LM state resident in registers / LDS for all <= max_iterations iterations;
-//   smpc_eval_kernel<NB>   K1: one residual + Jacobian sweep, rows written to HBM (parity + roofline runs).
+// Kernels (one 64-lane wavefront per workgroup, split into 64/W scene slots; see smpc_device.hpp / smpc_lm.hpp):
+//   smpc_solve_kernel<NB,W>  persistent sweep engine: whole ceres::Solve-equivalent (reference
+//                            src/optimizer.cpp:241-446) per scene, LM state resident in registers / LDS for all
+//                            <= max_iterations iterations, scenes pulled from a device-side queue;
+//   smpc_eval_kernel<NB,W>   K1: one residual + Jacobian sweep, rows written to HBM (parity + roofline runs).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -12,73 +13,6 @@
 #include <vector>
 
 #include "smpc_lm.hpp"
-
-namespace smpc {
-
-template <int NB>
-__device__ inline bool init_ctx(const KParams& k, Ctx<NB>& c, double* lds) {
-  c.kp = &k;
-  c.scene = blockIdx.x;
-  c.lane = lane_id();
-  c.lds = lds;
-  c.L = make_layout(k.T, k.N, 2 * NB);
-  const size_t s = c.scene;
-  c.has_people = (k.N > 0) && (k.has_people ? k.has_people[s] != 0 : true);
-  c.x0 = k.pose0[3 * s];
-  c.y0 = k.pose0[3 * s + 1];
-  c.yaw0 = k.pose0[3 * s + 2];
-  c.goal_yaw = k.goal_yaw[s];
-  const size_t cm = (size_t)k.size_x * k.size_y;
-  c.map = k.costmap + (k.costmap_shared ? 0 : cm * s);
-  c.ox = k.costmap_origin[k.costmap_shared ? 0 : 2 * s];
-  c.oy = k.costmap_origin[k.costmap_shared ? 1 : 2 * s + 1];
-  c.path_pts = k.path_pts + s * (k.T + 1) * 2;
-  return true;
-}
-
-template <int NB>
-__global__ __launch_bounds__(64) void smpc_solve_kernel(const KParams k) {
-  extern __shared__ double lds[];
-  Ctx<NB> c;
-  init_ctx<NB>(k, c, lds);
-  setup_scene<NB>(c);
-  solve_scene<NB>(c);
-}
-
-template <int NB>
-__global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
-  extern __shared__ double lds[];
-  constexpr int P = 2 * NB;
-  Ctx<NB> c;
-  init_ctx<NB>(k, c, lds);
-  setup_scene<NB>(c);
-  double x[P];
-  const size_t s = c.scene;
-#pragma unroll
-  for (int q = 0; q < P; ++q) x[q] = k.e_x[s * P + q];
-  Gram<P> G;
-  bool finite;
-  double* out_r = k.e_residuals ? k.e_residuals + s * k.e_M : nullptr;
-  double* out_J = k.e_jacobian ? k.e_jacobian + s * (size_t)k.e_M * P : nullptr;
-  // rows a scene without people does not have stay zero
-  if (!c.has_people) {
-    const int M5 = 5 * k.T + k.nfeas;
-    for (int i = M5 + c.lane; i < k.e_M; i += kWave) {
-      if (out_r) out_r[i] = 0.0;
-      if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)i * P + q] = 0.0;
-    }
-  }
-  sweep<NB>(c, x, G, finite, out_r, out_J);
-  if (c.lane == 0 && k.e_cost) k.e_cost[s] = 0.5 * G.v[Gram<P>::idx(P, P)];
-  if (k.e_gradient && c.lane < P) {
-    double v = 0.0;
-#pragma unroll
-    for (int q = 0; q < P; ++q) v = (q == c.lane) ? G.v[Gram<P>::idx(q, P)] : v;
-    k.e_gradient[s * P + c.lane] = v;
-  }
-}
-
-}  // namespace smpc
 
 // ================================================================================================
 // Host side of the C ABI
@@ -119,26 +53,30 @@ Dims make_dims(const smpc_params& p, int T, bool has_people) {
 struct smpc_handle {
   smpc_params prm;
   int device;
+  int num_cu;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   bool timed;
+  int* queue;  // device-side scene queue head
 };
 
 namespace {
 
 using KernelFn = void (*)(const smpc::KParams);
 
-template <int NB> KernelFn solve_fn() { return smpc::smpc_solve_kernel<NB>; }
-template <int NB> KernelFn eval_fn() { return smpc::smpc_eval_kernel<NB>; }
+template <int NB> KernelFn pick_w(int W, bool eval) {
+  if (W == 32) return eval ? smpc::smpc_eval_kernel<NB, 32> : smpc::smpc_solve_kernel<NB, 32>;
+  return eval ? smpc::smpc_eval_kernel<NB, 64> : smpc::smpc_solve_kernel<NB, 64>;
+}
 
-KernelFn pick(int nb, bool eval) {
+KernelFn pick(int nb, int W, bool eval) {
   switch (nb) {
-    case 1: return eval ? eval_fn<1>() : solve_fn<1>();
-    case 2: return eval ? eval_fn<2>() : solve_fn<2>();
-    case 3: return eval ? eval_fn<3>() : solve_fn<3>();
-    case 4: return eval ? eval_fn<4>() : solve_fn<4>();
-    case 5: return eval ? eval_fn<5>() : solve_fn<5>();
-    case 6: return eval ? eval_fn<6>() : solve_fn<6>();
+    case 1: return pick_w<1>(W, eval);
+    case 2: return pick_w<2>(W, eval);
+    case 3: return pick_w<3>(W, eval);
+    case 4: return pick_w<4>(W, eval);
+    case 5: return pick_w<5>(W, eval);
+    case 6: return pick_w<6>(W, eval);
     default: return nullptr;
   }
 }
@@ -153,7 +91,7 @@ int validate(const smpc_handle* h, const smpc_scene_batch* sb, Dims* d) {
   *d = make_dims(h->prm, sb->T, true);
   if (sb->T + 1 > smpc::kWave) { set_error("T + 1 > 64 rollout poses is not supported by the one-wave-per-scene mapping"); return SMPC_ERR_UNSUPPORTED; }
   if (sb->N > smpc::kWave) { set_error("N > 64 agents is not supported"); return SMPC_ERR_UNSUPPORTED; }
-  if (!pick(d->nb, false)) { set_error("number of parameter blocks not instantiated (nb must be 1..6)"); return SMPC_ERR_UNSUPPORTED; }
+  if (!pick(d->nb, 64, false)) { set_error("number of parameter blocks not instantiated (nb must be 1..6)"); return SMPC_ERR_UNSUPPORTED; }
   return SMPC_OK;
 }
 
@@ -194,14 +132,28 @@ struct Staging {
 
 #define SMPC_TRY(expr) do { int _rc = (expr); if (_rc != SMPC_OK) return _rc; } while (0)
 
-int launch(smpc_handle* h, KernelFn fn, const smpc::KParams& k) {
-  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P);
-  const size_t shmem = (size_t)L.total * sizeof(double);
+int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
+  const int W = smpc::slot_width(k.T, k.N);
+  const int S = smpc::kWave / W;
+  KernelFn fn = pick(k.nb, W, eval);
+  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, !eval);
+  const size_t shmem = ((size_t)S * L.total + smpc::wave_extra_doubles(k.P, W)) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
   if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (k.B == 0) return SMPC_OK;
+  int grid = (k.B + S - 1) / S;
+  if (!eval) {
+    // persistent sweep engine: no more waves than can be resident; scenes come from the queue
+    int per_cu = 0;
+    SMPC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), smpc::kWave, shmem));
+    if (per_cu < 1) per_cu = 1;
+    const int resident = per_cu * h->num_cu;
+    if (grid > resident) grid = resident;
+    k.queue = h->queue;
+    SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
+  }
   SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(fn, dim3(k.B), dim3(smpc::kWave), shmem, h->stream, k);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(smpc::kWave), shmem, h->stream, k);
   SMPC_HIP_CHECK(hipGetLastError());
   SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
@@ -283,7 +235,12 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
   h->device = device;
   h->stream = nullptr;
   h->timed = false;
+  h->queue = nullptr;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); delete h; return nullptr; }
+  h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { set_error("hipEventCreate failed"); delete h; return nullptr; }
+  if (hipMalloc(reinterpret_cast<void**>(&h->queue), sizeof(int)) != hipSuccess) { set_error("hipMalloc(queue) failed"); delete h; return nullptr; }
   return h;
 }
 
@@ -291,6 +248,7 @@ void smpc_destroy(smpc_handle* h) {
   if (!h) return;
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
+  if (h->queue) (void)hipFree(h->queue);
   delete h;
 }
 
@@ -321,7 +279,7 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   if (sb->on_device) {
     k.o_params = out->params; k.o_cmds = out->cmds; k.o_path = out->path; k.o_status = out->status; k.o_reason = out->reason;
     k.o_iterations = out->iterations; k.o_evaluations = out->evaluations; k.o_initial_cost = out->initial_cost; k.o_final_cost = out->final_cost;
-    return launch(h, pick(d.nb, false), k);
+    return launch(h, false, k);
   }
   SMPC_TRY(st.out(out->params, B * d.P, &k.o_params));
   SMPC_TRY(st.out(out->cmds, B * (T + 1) * 2, &k.o_cmds));
@@ -332,7 +290,7 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   SMPC_TRY(st.out(out->evaluations, B, &k.o_evaluations));
   SMPC_TRY(st.out(out->initial_cost, B, &k.o_initial_cost));
   SMPC_TRY(st.out(out->final_cost, B, &k.o_final_cost));
-  SMPC_TRY(launch(h, pick(d.nb, false), k));
+  SMPC_TRY(launch(h, false, k));
   SMPC_TRY(down(out->params, k.o_params, B * d.P, h->stream));
   SMPC_TRY(down(out->cmds, k.o_cmds, B * (T + 1) * 2, h->stream));
   SMPC_TRY(down(out->path, k.o_path, B * (T + 1) * 3, h->stream));
@@ -359,14 +317,14 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* pa
   if (sb->on_device) {
     k.e_x = params;
     k.e_residuals = out->residuals; k.e_jacobian = out->jacobian; k.e_cost = out->cost; k.e_gradient = out->gradient;
-    return launch(h, pick(d.nb, true), k);
+    return launch(h, true, k);
   }
   SMPC_TRY(st.up(params, B * d.P, &k.e_x, h->stream));
   SMPC_TRY(st.out(out->residuals, B * d.M, &k.e_residuals));
   SMPC_TRY(st.out(out->jacobian, B * d.M * d.P, &k.e_jacobian));
   SMPC_TRY(st.out(out->cost, B, &k.e_cost));
   SMPC_TRY(st.out(out->gradient, B * d.P, &k.e_gradient));
-  SMPC_TRY(launch(h, pick(d.nb, true), k));
+  SMPC_TRY(launch(h, true, k));
   SMPC_TRY(down(out->residuals, k.e_residuals, B * d.M, h->stream));
   SMPC_TRY(down(out->jacobian, k.e_jacobian, B * d.M * d.P, h->stream));
   SMPC_TRY(down(out->cost, k.e_cost, B, h->stream));

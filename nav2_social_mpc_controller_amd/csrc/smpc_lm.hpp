@@ -1,7 +1,12 @@
-// smpc_lm.hpp — per-wave Levenberg-Marquardt driver (the ceres::Solve call of reference src/optimizer.cpp:381,
-// options :117-131) and the post-solve unpack (src/optimizer.cpp:390-446). Algorithm = Ceres' trust-region
-// minimizer with bounds as specified in SURVEY.md Appendix A (A.4 .. A.11). Every quantity here is uniform
-// across the 64 lanes of the wave; only sweep() is lane-parallel.
+// smpc_lm.hpp — per-slot Levenberg-Marquardt state machine (the ceres::Solve call of reference
+// src/optimizer.cpp:381, options :117-131) and the post-solve unpack (src/optimizer.cpp:390-446).
+// Algorithm = Ceres' trust-region minimizer with bounds as specified in SURVEY.md Appendix A (A.4 .. A.11).
+//
+// A wave is a persistent "sweep engine": every trip of the main loop runs ONE sweep() for all slots of the wave
+// at each slot's current trial point, then each slot advances its own LM state (phases below) and produces its
+// next trial point, or finishes its scene and pulls the next one from the global scene queue. Slots never wait for
+// each other: iteration counts and line-search lengths differ per scene, the sweep is the only shared code.
+// Every LM quantity is uniform across the W lanes of a slot (computed redundantly, LM vectors parked in LDS).
 #pragma once
 
 #include "smpc_device.hpp"
@@ -123,7 +128,7 @@ struct Sample {
 // LineSearch::InterpolatingPolynomialMinimizingStepSize with CUBIC interpolation:
 // fit a polynomial through {lowerbound, current[, previous]} (values and directional derivatives), minimise on
 // [lo, hi]. scratch: >= 96 doubles of LDS.
-__device__ inline double interpolate_step(const Sample& lower, const Sample& previous, const Sample& current,
+__device__ __attribute__((noinline)) double interpolate_step(const Sample& lower, const Sample& previous, const Sample& current,
                                           double lo, double hi, double* scratch) {
   if (!current.value_valid) return fmin(fmax(current.x * 0.5, lo), hi);
   double* A = scratch;          // 36
@@ -187,6 +192,222 @@ __device__ inline double interpolate_step(const Sample& lower, const Sample& pre
   return opt_x;
 }
 
+// ---- register-resident fast paths of the line-search interpolation (same algorithm as above, no LDS loops) ----
+
+// Full-pivot Gaussian elimination of an n x n system held in registers; pivot choice and operation order follow
+// fullpiv_solve() exactly (row-major scan, strict '>'), swaps are done with selects.
+template <int n>
+__device__ inline void fullpiv_solve_reg(double (&A)[n][n], double (&b)[n], double (&out)[n]) {
+  int perm[n];
+#pragma unroll
+  for (int i = 0; i < n; ++i) perm[i] = i;
+  bool alive = true;  // false once a zero pivot block is met (remaining rhs := 0)
+#pragma unroll
+  for (int kk = 0; kk < n; ++kk) {
+    int pr = kk, pc = kk;
+    double best = -1.0;
+#pragma unroll
+    for (int i = kk; i < n; ++i) {
+#pragma unroll
+      for (int j = kk; j < n; ++j) {
+        const double v = fabs(A[i][j]);
+        const bool better = v > best;
+        best = better ? v : best; pr = better ? i : pr; pc = better ? j : pc;
+      }
+    }
+    if (alive && best == 0.0) {
+      alive = false;
+#pragma unroll
+      for (int i = kk; i < n; ++i) b[i] = 0.0;
+    }
+    if (alive) {
+#pragma unroll
+      for (int i = kk + 1; i < n; ++i) {
+        const bool sw = (pr == i);
+#pragma unroll
+        for (int j = 0; j < n; ++j) { const double t = A[i][j]; A[i][j] = sw ? A[kk][j] : t; A[kk][j] = sw ? t : A[kk][j]; }
+        const double t = b[i]; b[i] = sw ? b[kk] : t; b[kk] = sw ? t : b[kk];
+      }
+#pragma unroll
+      for (int j = kk + 1; j < n; ++j) {
+        const bool sw = (pc == j);
+#pragma unroll
+        for (int i = 0; i < n; ++i) { const double t = A[i][j]; A[i][j] = sw ? A[i][kk] : t; A[i][kk] = sw ? t : A[i][kk]; }
+        const int t = perm[j]; perm[j] = sw ? perm[kk] : t; perm[kk] = sw ? t : perm[kk];
+      }
+#pragma unroll
+      for (int i = kk + 1; i < n; ++i) {
+        const double f = A[i][kk] / A[kk][kk];
+#pragma unroll
+        for (int j = kk; j < n; ++j) A[i][j] -= f * A[kk][j];
+        b[i] -= f * b[kk];
+      }
+    }
+  }
+  double z[n];
+#pragma unroll
+  for (int i = n - 1; i >= 0; --i) {
+    double v = b[i];
+#pragma unroll
+    for (int kk = i + 1; kk < n; ++kk) v -= A[i][kk] * z[kk];
+    z[i] = (A[i][i] == 0.0) ? 0.0 : v / A[i][i];
+  }
+#pragma unroll
+  for (int t = 0; t < n; ++t) out[t] = 0.0;
+#pragma unroll
+  for (int i = 0; i < n; ++i) {
+#pragma unroll
+    for (int t = 0; t < n; ++t) out[t] = (perm[i] == t) ? z[i] : out[t];
+  }
+}
+
+template <int nc> __device__ inline double eval_poly_reg(const double (&p)[nc], double x) {
+  double v = 0.0;
+#pragma unroll
+  for (int i = 0; i < nc; ++i) v = v * x + p[i];
+  return v;
+}
+
+// Real parts of the 4 roots of a quartic q[0] x^4 + ... + q[4] (q[0] != 0): Aberth-Ehrlich with the four roots
+// iterated simultaneously on 4 neighbouring lanes (lane & 3 = root index), same start points and stopping rule
+// as poly_roots_real(). Returns all four real parts in every lane.
+__device__ inline void quartic_roots_real_lanes(const double (&q)[5], double (&roots)[4]) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 3, base = lane & ~3;
+  double cm[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) cm[i] = q[i] / q[0];
+  double radius = 0.0;
+  radius = fmax(radius, fabs(cm[1]));
+  radius = fmax(radius, sqrt(fabs(cm[2])));
+  radius = fmax(radius, cbrt(fabs(cm[3])));
+  radius = fmax(radius, sqrt(sqrt(fabs(cm[4]))));
+  radius = fmax(2.0 * radius, 1e-300);
+  double sn, cs;
+  sincos(2.0 * M_PI * r / 4 + 0.4, &sn, &cs);
+  double zr = radius * cs, zi = radius * sn;
+  for (int it = 0; it < 200; ++it) {
+    double pr = cm[0], pi = 0.0, dr = 0.0, di = 0.0;
+#pragma unroll
+    for (int kk = 1; kk <= 4; ++kk) {
+      const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
+      dr = ndr; di = ndi;
+      const double npr = pr * zr - pi * zi + cm[kk], npi = pr * zi + pi * zr;
+      pr = npr; pi = npi;
+    }
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double ojr = __shfl(zr, base + j, 64), oji = __shfl(zi, base + j, 64);
+      const double er = zr - ojr, ei = zi - oji;
+      const double ee = er * er + ei * ei;
+      if (j != r) { sr += er / ee; si += -ei / ee; }
+    }
+    double rel = 0.0;
+    if (!(pr == 0.0 && pi == 0.0)) {
+      const double dd = dr * dr + di * di;
+      const double rr = (pr * dr + pi * di) / dd, ri = (pi * dr - pr * di) / dd;
+      const double qr = 1.0 - (rr * sr - ri * si), qi = -(rr * si + ri * sr);
+      const double qq = qr * qr + qi * qi;
+      const double str = (rr * qr + ri * qi) / qq, sti = (ri * qr - rr * qi) / qq;
+      zr -= str; zi -= sti;
+      rel = sqrt(str * str + sti * sti) / fmax(1e-300, sqrt(zr * zr + zi * zi));
+    }
+    rel = fmax(rel, __shfl_xor(rel, 1, 64));
+    rel = fmax(rel, __shfl_xor(rel, 2, 64));
+    if (rel < 1e-15) break;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) roots[j] = __shfl(zr, base + j, 64);
+}
+
+// MinimizeInterpolatingPolynomial for the two common shapes: {lower, current} with all values and gradients valid
+// (cubic, nc = 4) and {lower, current, previous} (quintic, nc = 6). Returns false if the shape is not covered.
+__device__ __attribute__((noinline)) bool interpolate_step_fast(const Sample& lower, const Sample& previous, const Sample& current,
+                                             double lo, double hi, double& step_size) {
+  if (!(lower.value_valid && lower.gradient_valid && current.value_valid && current.gradient_valid)) return false;
+  const bool use_prev = previous.value_valid;
+  if (use_prev && !previous.gradient_valid) return false;
+  double opt_x = (lo + hi) / 2.0, opt_v;
+  if (!use_prev) {
+    constexpr int nc = 4;
+    double A[nc][nc], b[nc], poly[nc];
+    // rows: value(lower), gradient(lower), value(current), gradient(current); column j <-> x^(3-j)
+    const double x0 = lower.x, x1 = current.x;
+    A[0][3] = 1.0; A[0][2] = x0; A[0][1] = x0 * x0; A[0][0] = x0 * x0 * x0;
+    A[1][3] = 0.0; A[1][2] = 1.0; A[1][1] = 2.0 * x0; A[1][0] = 3.0 * (x0 * x0);
+    A[2][3] = 1.0; A[2][2] = x1; A[2][1] = x1 * x1; A[2][0] = x1 * x1 * x1;
+    A[3][3] = 0.0; A[3][2] = 1.0; A[3][1] = 2.0 * x1; A[3][0] = 3.0 * (x1 * x1);
+    b[0] = lower.value; b[1] = lower.gradient; b[2] = current.value; b[3] = current.gradient;
+    fullpiv_solve_reg<nc>(A, b, poly);
+    opt_v = eval_poly_reg<nc>(poly, opt_x);
+    const double vlo = eval_poly_reg<nc>(poly, lo);
+    if (vlo < opt_v) { opt_v = vlo; opt_x = lo; }
+    const double vhi = eval_poly_reg<nc>(poly, hi);
+    if (vhi < opt_v) { opt_v = vhi; opt_x = hi; }
+    // derivative 3 p0 x^2 + 2 p1 x + p2, roots as poly_roots_real() finds them (leading zeros stripped)
+    const double qa = 3.0 * poly[0], qb = 2.0 * poly[1], qc = poly[2];
+    double r0 = 0.0, r1 = 0.0;
+    int nr = 0;
+    if (qa != 0.0) {
+      const double D = qb * qb - 4 * qa * qc;
+      const double sD = sqrt(fabs(D));
+      if (D >= 0) {
+        if (qb >= 0) { r0 = (-qb - sD) / (2.0 * qa); r1 = (2.0 * qc) / (-qb - sD); }
+        else { r0 = (2.0 * qc) / (-qb + sD); r1 = (-qb + sD) / (2.0 * qa); }
+      } else { r0 = -qb / (2.0 * qa); r1 = r0; }
+      nr = 2;
+    } else if (qb != 0.0) { r0 = -qc / qb; nr = 1; }
+    if (nr >= 1 && !(r0 < lo || r0 > hi)) { const double v = eval_poly_reg<nc>(poly, r0); if (v < opt_v) { opt_v = v; opt_x = r0; } }
+    if (nr >= 2 && !(r1 < lo || r1 > hi)) { const double v = eval_poly_reg<nc>(poly, r1); if (v < opt_v) { opt_v = v; opt_x = r1; } }
+    if (!(lower.x < lo || lower.x > hi)) { const double v = eval_poly_reg<nc>(poly, lower.x); if (v < opt_v) { opt_v = v; opt_x = lower.x; } }
+    if (!(current.x < lo || current.x > hi)) { const double v = eval_poly_reg<nc>(poly, current.x); if (v < opt_v) { opt_v = v; opt_x = current.x; } }
+    step_size = opt_x;
+    return true;
+  }
+  constexpr int nc = 6;
+  double A[nc][nc], b[nc], poly[nc];
+  const double xs[3] = {lower.x, current.x, previous.x};
+  const double vs[3] = {lower.value, current.value, previous.value};
+  const double gsv[3] = {lower.gradient, current.gradient, previous.gradient};
+#pragma unroll
+  for (int smp = 0; smp < 3; ++smp) {
+    const double xv = xs[smp];
+    double pw = 1.0;
+#pragma unroll
+    for (int j = 5; j >= 0; --j) { A[2 * smp][j] = pw; pw *= xv; }
+    pw = 1.0;
+    A[2 * smp + 1][5] = 0.0;
+#pragma unroll
+    for (int j = 4; j >= 0; --j) { A[2 * smp + 1][j] = (5 - j) * pw; pw *= xv; }
+    b[2 * smp] = vs[smp];
+    b[2 * smp + 1] = gsv[smp];
+  }
+  fullpiv_solve_reg<nc>(A, b, poly);
+  double dq[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) dq[i] = (5 - i) * poly[i];
+  if (dq[0] == 0.0) return false;  // degenerate leading coefficient: generic path
+  opt_v = eval_poly_reg<nc>(poly, opt_x);
+  const double vlo = eval_poly_reg<nc>(poly, lo);
+  if (vlo < opt_v) { opt_v = vlo; opt_x = lo; }
+  const double vhi = eval_poly_reg<nc>(poly, hi);
+  if (vhi < opt_v) { opt_v = vhi; opt_x = hi; }
+  double roots[4];
+  quartic_roots_real_lanes(dq, roots);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double rt = roots[i];
+    if (!(rt < lo || rt > hi)) { const double v = eval_poly_reg<nc>(poly, rt); if (v < opt_v) { opt_v = v; opt_x = rt; } }
+  }
+#pragma unroll
+  for (int smp = 0; smp < 3; ++smp) {
+    if (!(xs[smp] < lo || xs[smp] > hi)) { const double v = eval_poly_reg<nc>(poly, xs[smp]); if (v < opt_v) { opt_v = v; opt_x = xs[smp]; } }
+  }
+  step_size = opt_x;
+  return true;
+}
+
 // In-register Cholesky solve of (Hs + diag(D2)) y = gs for P <= 20 (fully unrolled, packed lower triangle).
 template <int P>
 __device__ inline bool cholesky_solve(const double* Hs, const double* D2, const double* gs, double (&y)[P]) {
@@ -236,228 +457,334 @@ __device__ inline double yaw_roundtrip(double yaw) {
   return atan2(2.0 * (cz * sz), cz * cz - sz * sz);
 }
 
-template <int NB>
-__device__ inline void solve_scene(Ctx<NB>& c) {
+
+enum Phase { PH_FETCH = 0, PH_INIT = 1, PH_LS = 2, PH_REEVAL = 3, PH_DONE = 4, PH_IDLE = 5 };
+
+// Slot-uniform LM scalars parked in LDS (offsets into the scal[] block).
+enum Scal { S_COST = 0, S_XNORM, S_GMAX, S_RADIUS, S_DECF, S_MCC, S_GD0, S_DIRMAX, S_PREV_X, S_PREV_V, S_PREV_G,
+            S_CUR_X, S_CUR_V, S_CUR_G, S_INITIAL_COST, S_COUNT };
+
+struct LmRegs {  // slot-uniform integers / flags kept in registers
+  int phase, iter, evals, num_invalid, ls_iters, n_samples, status, reason;
+  bool step_successful, at_least_one, prev_vv, prev_gv, cur_vv, cur_gv;
+};
+
+template <int NB, int W>
+__global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
   constexpr int P = 2 * NB;
-  const KParams& k = *c.kp;
+  constexpr int S = kWave / W;
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / W;
+  Ctx c;
+  c.kp = &k;
+  c.sl = lane - slot * W;
+  c.L = make_layout(k.T, k.N, P, true);
+  c.lds = lds_all + (size_t)slot * c.L.total;
+  c.wave_lds = lds_all + (size_t)S * c.L.total;
+  c.slot = slot;
   const smpc_params& prm = k.prm;
-  const int lane = c.lane, T = k.T;
-  double* lm = c.lds + c.L.lm;
-  double* Hs = lm;                 // [P*P] scaled J^T J at the current point
-  double* gs = Hs + P * P;         // [P]   scaled gradient
-  double* gu = gs + P;             // [P]   unscaled gradient
+  const int T = k.T;
+  double* Hs = c.lds + c.L.lm;   // [P*P] scaled J^T J at the current point
+  double* gs = Hs + P * P;       // [P] scaled gradient
+  double* gu = gs + P;           // [P] unscaled gradient
+  double* xc = gu + P;           // [P] current point
+  double* xt = xc + P;           // [P] trial point (input of the sweep)
+  double* dl = xt + P;           // [P] delta (unscaled step of this iteration)
+  double* sc = dl + P;           // [P] Jacobi scaling
+  double* sv = sc + P;           // scalars [24]
   double* scratch = c.lds + c.L.scratch;
+  const int blast = (k.CH - 1) / k.bl;
+  auto lo = [&](int q) -> double { return (q / 2 < k.nbounded) ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308; };
+  auto hi = [&](int q) -> double { return (q / 2 < k.nbounded) ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308; };
 
-  double lo[P], hi[P], x[P], scale[P];
-#pragma unroll
-  for (int q = 0; q < P; ++q) { lo[q] = -1.7976931348623157e308; hi[q] = 1.7976931348623157e308; }
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    if (b < k.nbounded) { lo[2 * b] = prm.v_min; hi[2 * b] = prm.v_max; lo[2 * b + 1] = prm.w_min; hi[2 * b + 1] = prm.w_max; }
-  }
-  const double* xin = k.init_params + (size_t)c.scene * P;
-#pragma unroll
-  for (int q = 0; q < P; ++q) x[q] = clampd(xin[q] + 0.0, lo[q], hi[q]);  // Plus(x, 0): project the start point
-  double x_norm = 0.0;
-#pragma unroll
-  for (int q = 0; q < P; ++q) x_norm += x[q] * x[q];
-  x_norm = sqrt(x_norm);
+  LmRegs R;
+  R.phase = PH_FETCH;
+  R.iter = R.evals = R.num_invalid = R.ls_iters = R.n_samples = 0;
+  R.status = SMPC_NO_CONVERGENCE; R.reason = SMPC_REASON_MAX_ITERATIONS;
+  R.step_successful = R.at_least_one = R.prev_vv = R.prev_gv = R.cur_vv = R.cur_gv = false;
+  bool ever_loaded = false;
 
-  int status = SMPC_NO_CONVERGENCE, reason = SMPC_REASON_MAX_ITERATIONS, iter = 0, evals = 0;
-  double cost = 0.0, initial_cost = 0.0, gmax = 0.0;
-  {
-    Gram<P> G;
-    bool finite;
-    sweep<NB>(c, x, G, finite, nullptr, nullptr);
-    ++evals;
-    cost = 0.5 * G.v[Gram<P>::idx(P, P)];
-    initial_cost = cost;
-    if (!finite) { status = SMPC_FAILURE; reason = SMPC_REASON_EVAL_FAILED; }
+  for (;;) {
+    // ---------------------------------------------------------------- fetch the next scene for idle slots
+    if (R.phase == PH_FETCH) {
+      int scene = 0;
+      if (c.sl == 0) scene = atomicAdd(k.queue, 1);
+      scene = __shfl(scene, slot * W, 64);
+      if (scene < k.B) {
+        load_scene<W>(c, scene);
+        ever_loaded = true;
+        const double* xin = k.init_params + (size_t)scene * P;
+        double xn = 0.0;
 #pragma unroll
-    for (int q = 0; q < P; ++q) scale[q] = 1.0 / (1.0 + sqrt(G.v[Gram<P>::idx(q, q)]));  // Jacobi scaling, fixed at iteration 0
-#pragma unroll
-    for (int a = 0; a < P; ++a) {
-#pragma unroll
-      for (int b = 0; b < P; ++b) Hs[a * P + b] = G.H(a, b) * scale[a] * scale[b];
-      const double g = G.v[Gram<P>::idx(a, P)];
-      gu[a] = g; gs[a] = g * scale[a];
-      gmax = fmax(gmax, fabs(x[a] - clampd(x[a] - g, lo[a], hi[a])));
-    }
-    __syncthreads();
-  }
-
-  if (status != SMPC_FAILURE) {
-    double radius = 1e4, decrease_factor = 2.0;
-    int num_invalid = 0;
-    bool step_successful = true, at_least_one = false;
-    for (;;) {
-      if (iter >= prm.max_iterations) { status = SMPC_NO_CONVERGENCE; reason = SMPC_REASON_MAX_ITERATIONS; break; }
-      if (step_successful && gmax <= prm.gradient_tol && !prm.fixed_iterations) { status = SMPC_CONVERGENCE; reason = SMPC_REASON_GRADIENT_TOL; break; }
-      if (radius <= 1e-32) { status = SMPC_CONVERGENCE; reason = SMPC_REASON_MIN_RADIUS; break; }
-      ++iter;
-      step_successful = false;
-
-      // LM step: (Hs + D^2) y = gs, step = -y (A.6); model cost change (A.7)
-      double step[P], D2[P];
-#pragma unroll
-      for (int q = 0; q < P; ++q) {
-        const double d = sqrt(clampd(Hs[q * P + q], 1e-6, 1e32) / radius);
-        D2[q] = d * d;
-      }
-      bool valid = cholesky_solve<P>(Hs, D2, gs, step);
-      double mcc = 0.0;
-#pragma unroll
-      for (int q = 0; q < P; ++q) { if (!isfinite(step[q])) valid = false; step[q] = -step[q]; }
-      if (valid) {
-        double sg = 0.0, sHs = 0.0;
-#pragma unroll
-        for (int a = 0; a < P; ++a) {
-          sg += step[a] * gs[a];
-          double row = 0.0;
-#pragma unroll
-          for (int b = 0; b < P; ++b) row += Hs[a * P + b] * step[b];
-          sHs += step[a] * row;
+        for (int q = 0; q < P; ++q) {
+          const double v = clampd(xin[q] + 0.0, lo(q), hi(q));  // Plus(x, 0): project the start point (A.4)
+          xc[q] = v; xt[q] = v; xn += v * v;
         }
-        mcc = -sg - 0.5 * sHs;
-        valid = mcc > 0.0;
-      }
-      if (!valid) {
-        if (++num_invalid >= 5) { status = SMPC_FAILURE; reason = SMPC_REASON_INVALID_STEPS; break; }
-        radius = radius / decrease_factor; decrease_factor *= 2.0;
-        continue;
-      }
-      num_invalid = 0;
-      double delta[P];
+        sv[S_XNORM] = sqrt(xn);
+        R.phase = PH_INIT;
+        R.iter = 0; R.evals = 0; R.num_invalid = 0;
+        R.status = SMPC_NO_CONVERGENCE; R.reason = SMPC_REASON_MAX_ITERATIONS;
+        R.step_successful = true; R.at_least_one = false;
+      } else {
+        if (!ever_loaded) {  // keep the sweep's memory accesses in bounds for a slot that never got a scene
+          load_scene<W>(c, 0);
+          ever_loaded = true;
 #pragma unroll
-      for (int q = 0; q < P; ++q) delta[q] = step[q] * scale[q];
+          for (int q = 0; q < P; ++q) xt[q] = 0.0;
+        }
+        R.phase = PH_IDLE;
+      }
+    }
+    if (__all(R.phase == PH_IDLE)) break;
 
-      // projected Armijo line search (A.8); every sample is a full sweep (value + gradient, CUBIC interpolation)
-      double gd0 = 0.0, dirmax = 0.0;
+    // ---------------------------------------------------------------- one sweep for every slot of the wave
+    const GramView GH = sweep<NB, W>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    const bool finite = gram_finite<P>(GH);
+    const double val = 0.5 * GH(P, P);
+    bool new_iteration = false;
+
+    // ---------------------------------------------------------------- advance the slot's state machine
+    auto adopt_trial_point = [&]() {  // x <- xt, Hs/gs/gu/gmax from G (scaled by the fixed Jacobi scaling)
+      double xn = 0.0, gmax = 0.0;
 #pragma unroll
-      for (int q = 0; q < P; ++q) { gd0 += gu[q] * delta[q]; dirmax = fmax(dirmax, fabs(delta[q])); }
-      Sample lower{0.0, cost, gd0, true, true};
-      Sample previous{0.0, 0.0, 0.0, false, false}, current{1.0, 0.0, 0.0, false, false};
-      double xt[P];
-      Gram<P> G;
-      bool finite;
-      auto sample_at = [&](double alpha, Sample& s) {
+      for (int a = 0; a < P; ++a) {
+        const double xa = xt[a];
+        xc[a] = xa;
+        xn += xa * xa;
+        const double sa = sc[a];
 #pragma unroll
-        for (int q = 0; q < P; ++q) xt[q] = clampd(x[q] + alpha * delta[q], lo[q], hi[q]);
-        sweep<NB>(c, xt, G, finite, nullptr, nullptr);
-        ++evals;
-        s.x = alpha;
-        s.value = 0.5 * G.v[Gram<P>::idx(P, P)];
-        s.value_valid = finite && isfinite(s.value);
-        double gd = 0.0;
-#pragma unroll
-        for (int q = 0; q < P; ++q) gd += delta[q] * G.v[Gram<P>::idx(q, P)];
-        s.gradient = gd;
-        s.gradient_valid = s.value_valid && isfinite(gd);
-      };
-      sample_at(1.0, current);
-      bool ls_ok = false;
-      int ls_iters = 0, n_samples = 1;
-      for (;;) {
-        if (current.value_valid && !(current.value > cost + 1e-4 * gd0 * current.x)) { ls_ok = true; break; }
-        ++ls_iters;
-        if (ls_iters >= 20) break;
-        const double step_size = interpolate_step(lower, previous, current, 1e-3 * current.x, 0.6 * current.x, scratch);
-        if (step_size * dirmax < 1e-9) break;
-        previous = current;
-        sample_at(step_size, current);
-        ++n_samples;
+        for (int b = 0; b < P; ++b) Hs[a * P + b] = GH(a, b) * sa * sc[b];
+        const double g = GH(a, P);
+        gu[a] = g; gs[a] = g * sa;
+        gmax = fmax(gmax, fabs(xa - clampd(xa - g, lo(a), hi(a))));
       }
-      if (ls_ok) {
-#pragma unroll
-        for (int q = 0; q < P; ++q) delta[q] *= current.x;
-      } else if (n_samples > 1) {
-        sample_at(1.0, current);  // line search failed: the candidate is the full step again
-      }
-      const double cand_cost = current.value_valid ? current.value : 1.7976931348623157e308;
+      sv[S_XNORM] = sqrt(xn);
+      sv[S_GMAX] = gmax;
+    };
+    auto candidate = [&]() {  // A.9 tests on the candidate = current trial point; A.10 strategy update
+      const double cost = sv[S_COST];
+      const double cand_cost = R.cur_vv ? sv[S_CUR_V] : 1.7976931348623157e308;
       double step_norm = 0.0;
 #pragma unroll
-      for (int q = 0; q < P; ++q) step_norm += (x[q] - xt[q]) * (x[q] - xt[q]);
+      for (int q = 0; q < P; ++q) { const double d = xc[q] - xt[q]; step_norm += d * d; }
       step_norm = sqrt(step_norm);
-      const bool tol_allowed = !prm.fixed_iterations && (!prm.tol_needs_successful_step || at_least_one);
-      if (tol_allowed && step_norm <= prm.param_tol * (x_norm + prm.param_tol)) { status = SMPC_CONVERGENCE; reason = SMPC_REASON_PARAMETER_TOL; break; }
+      const bool tol_allowed = !prm.fixed_iterations && (!prm.tol_needs_successful_step || R.at_least_one);
+      if (tol_allowed && step_norm <= prm.param_tol * (sv[S_XNORM] + prm.param_tol)) {
+        R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_PARAMETER_TOL; R.phase = PH_DONE; return;
+      }
       const double cost_change = cost - cand_cost;
-      if (tol_allowed && fabs(cost_change) <= prm.fn_tol * cost) { status = SMPC_CONVERGENCE; reason = SMPC_REASON_FUNCTION_TOL; break; }
-      const double rho = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : cost_change / mcc;
+      if (tol_allowed && fabs(cost_change) <= prm.fn_tol * cost) {
+        R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_FUNCTION_TOL; R.phase = PH_DONE; return;
+      }
+      const double rho = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : cost_change / sv[S_MCC];
       if (rho > 1e-3) {
-        x_norm = 0.0;
-        gmax = 0.0;
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < P; ++a) {
-          x[a] = xt[a];
-          x_norm += x[a] * x[a];
-#pragma unroll
-          for (int b = 0; b < P; ++b) Hs[a * P + b] = G.H(a, b) * scale[a] * scale[b];
-          const double g = G.v[Gram<P>::idx(a, P)];
-          gu[a] = g; gs[a] = g * scale[a];
-          gmax = fmax(gmax, fabs(x[a] - clampd(x[a] - g, lo[a], hi[a])));
-        }
-        __syncthreads();
-        x_norm = sqrt(x_norm);
-        cost = cand_cost;
-        step_successful = true; at_least_one = true;
+        adopt_trial_point();
+        sv[S_COST] = cand_cost;
+        R.step_successful = true; R.at_least_one = true;
         const double t = 2.0 * rho - 1.0;
-        radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-        radius = fmin(1e16, radius);
-        decrease_factor = 2.0;
+        sv[S_RADIUS] = fmin(1e16, sv[S_RADIUS] / fmax(1.0 / 3.0, 1.0 - t * t * t));
+        sv[S_DECF] = 2.0;
       } else {
-        radius = radius / decrease_factor; decrease_factor *= 2.0;
+        sv[S_RADIUS] = sv[S_RADIUS] / sv[S_DECF];
+        sv[S_DECF] *= 2.0;
       }
-    }
-  }
+      new_iteration = true;
+    };
 
-  // ---- outputs: params, a12 unpack (src/optimizer.cpp:390-446)
-  const size_t s = c.scene;
-  if (lane == 0) {
-    if (k.o_status) k.o_status[s] = status;
-    if (k.o_reason) k.o_reason[s] = reason;
-    if (k.o_iterations) k.o_iterations[s] = iter;
-    if (k.o_evaluations) k.o_evaluations[s] = evals;
-    if (k.o_initial_cost) k.o_initial_cost[s] = initial_cost;
-    if (k.o_final_cost) k.o_final_cost[s] = cost;
-  }
-  if (k.o_params && lane < P) {
-    double v = 0.0;
+    if (R.phase == PH_INIT) {
+      ++R.evals;
+      sv[S_COST] = val;
+      sv[S_INITIAL_COST] = val;
+      if (!finite) {
+        R.status = SMPC_FAILURE; R.reason = SMPC_REASON_EVAL_FAILED; R.phase = PH_DONE;
+      } else {
 #pragma unroll
-    for (int q = 0; q < P; ++q) v = (q == lane) ? x[q] : v;
-    k.o_params[s * P + lane] = v;
-  }
-  // saving_velocities[i], i = 0..T: block i/bl for i < CH, else the last block (:390-411)
-  const int blast = (k.CH - 1) / k.bl;
-  if (k.o_cmds) {
-    for (int i = lane; i <= T; i += kWave) {
-      const int b = (i < k.CH) ? i / k.bl : blast;
-      double v = 0.0, w = 0.0;
+        for (int q = 0; q < P; ++q) sc[q] = 1.0 / (1.0 + sqrt(GH(q, q)));  // Jacobi scaling (A.5)
+        adopt_trial_point();
+        sv[S_RADIUS] = 1e4; sv[S_DECF] = 2.0;
+        new_iteration = true;
+      }
+    } else if (R.phase == PH_LS) {
+      ++R.evals;
+      // record the sample just evaluated (LineSearchFunction::Evaluate, A.8)
+      double gd = 0.0;
 #pragma unroll
-      for (int q = 0; q < NB; ++q) { v = (q == b) ? x[2 * q] : v; w = (q == b) ? x[2 * q + 1] : w; }
-      k.o_cmds[(s * (T + 1) + i) * 2] = v;
-      k.o_cmds[(s * (T + 1) + i) * 2 + 1] = w;
+      for (int q = 0; q < P; ++q) gd += dl[q] * GH(q, P);
+      R.cur_vv = finite && isfinite(val);
+      R.cur_gv = R.cur_vv && isfinite(gd);
+      sv[S_CUR_V] = val; sv[S_CUR_G] = gd;
+      const double alpha = sv[S_CUR_X];
+      if (R.cur_vv && !(val > sv[S_COST] + 1e-4 * sv[S_GD0] * alpha)) {
+        // Armijo satisfied: delta *= alpha; the candidate is this very point
+#pragma unroll
+        for (int q = 0; q < P; ++q) dl[q] *= alpha;
+        candidate();
+      } else {
+        ++R.ls_iters;
+        bool failed = R.ls_iters >= 20;
+        double step_size = 0.0;
+        if (!failed) {
+          Sample lower{0.0, sv[S_COST], sv[S_GD0], true, true};
+          Sample previous{sv[S_PREV_X], sv[S_PREV_V], sv[S_PREV_G], R.prev_vv, R.prev_gv};
+          Sample current{alpha, val, gd, R.cur_vv, R.cur_gv};
+          if (!interpolate_step_fast(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, step_size))
+            step_size = interpolate_step(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, scratch);
+          failed = step_size * sv[S_DIRMAX] < 1e-9;
+        }
+        if (!failed) {
+          sv[S_PREV_X] = alpha; sv[S_PREV_V] = val; sv[S_PREV_G] = gd; R.prev_vv = R.cur_vv; R.prev_gv = R.cur_gv;
+          sv[S_CUR_X] = step_size;
+#pragma unroll
+          for (int q = 0; q < P; ++q) xt[q] = clampd(xc[q] + step_size * dl[q], lo(q), hi(q));
+          ++R.n_samples;
+        } else if (R.n_samples > 1) {
+          // line search failed: delta unchanged, the candidate is the full step again -> re-evaluate it
+#pragma unroll
+          for (int q = 0; q < P; ++q) xt[q] = clampd(xc[q] + dl[q], lo(q), hi(q));
+          R.phase = PH_REEVAL;
+        } else {
+          candidate();  // the only sample was the full step itself
+        }
+      }
+    } else if (R.phase == PH_REEVAL) {
+      ++R.evals;
+      R.cur_vv = finite && isfinite(val);
+      sv[S_CUR_V] = val;
+      candidate();
     }
-  }
-  if (k.o_path) {
-    // sequential re-roll with the reference's quaternion round trips; uniform, lane 0 stores
-    double px = c.x0, py = c.y0, yaw = yaw_roundtrip(c.yaw0);
-    for (int i = 0; i <= T; ++i) {
-      const int b = (i < k.CH) ? i / k.bl : blast;
-      double v = 0.0, w = 0.0;
+
+    // ---------------------------------------------------------------- start the next LM iteration (A.6, A.7)
+    if (new_iteration) {
+      for (;;) {
+        if (R.iter >= prm.max_iterations) { R.status = SMPC_NO_CONVERGENCE; R.reason = SMPC_REASON_MAX_ITERATIONS; R.phase = PH_DONE; break; }
+        if (R.step_successful && sv[S_GMAX] <= prm.gradient_tol && !prm.fixed_iterations) { R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_GRADIENT_TOL; R.phase = PH_DONE; break; }
+        if (sv[S_RADIUS] <= 1e-32) { R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_MIN_RADIUS; R.phase = PH_DONE; break; }
+        ++R.iter;
+        R.step_successful = false;
+        double step[P], D2[P];
+        const double radius = sv[S_RADIUS];
 #pragma unroll
-      for (int q = 0; q < NB; ++q) { v = (q == b) ? x[2 * q] : v; w = (q == b) ? x[2 * q + 1] : w; }
-      double sn, cs;
-      sincos(yaw, &sn, &cs);
-      px = px + v * cs * k.dt;
-      py = py + v * sn * k.dt;
-      yaw = yaw_roundtrip(yaw + w * k.dt);
-      if (lane == 0) {
-        double* o = k.o_path + (s * (T + 1) + i) * 3;
-        o[0] = px; o[1] = py; o[2] = yaw;
+        for (int q = 0; q < P; ++q) {
+          const double d = sqrt(clampd(Hs[q * P + q], 1e-6, 1e32) / radius);
+          D2[q] = d * d;
+        }
+        bool valid = cholesky_solve<P>(Hs, D2, gs, step);
+        double mcc = 0.0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) { if (!isfinite(step[q])) valid = false; step[q] = -step[q]; }
+        if (valid) {
+          double sg = 0.0, sHs = 0.0;
+#pragma unroll
+          for (int a = 0; a < P; ++a) {
+            sg += step[a] * gs[a];
+            double row = 0.0;
+#pragma unroll
+            for (int b = 0; b < P; ++b) row += Hs[a * P + b] * step[b];
+            sHs += step[a] * row;
+          }
+          mcc = -sg - 0.5 * sHs;
+          valid = mcc > 0.0;
+        }
+        if (!valid) {
+          if (++R.num_invalid >= 5) { R.status = SMPC_FAILURE; R.reason = SMPC_REASON_INVALID_STEPS; R.phase = PH_DONE; break; }
+          sv[S_RADIUS] = radius / sv[S_DECF]; sv[S_DECF] *= 2.0;
+          continue;
+        }
+        R.num_invalid = 0;
+        sv[S_MCC] = mcc;
+        double gd0 = 0.0, dirmax = 0.0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          const double d = step[q] * sc[q];
+          dl[q] = d;
+          gd0 += gu[q] * d;
+          dirmax = fmax(dirmax, fabs(d));
+          xt[q] = clampd(xc[q] + 1.0 * d, lo(q), hi(q));
+        }
+        sv[S_GD0] = gd0; sv[S_DIRMAX] = dirmax;
+        sv[S_CUR_X] = 1.0;
+        R.prev_vv = R.prev_gv = false;
+        R.ls_iters = 0; R.n_samples = 1;
+        R.phase = PH_LS;
+        break;
       }
     }
+
+    // ---------------------------------------------------------------- finished: outputs, a12 unpack
+    if (R.phase == PH_DONE) {
+      const size_t s = c.scene;
+      if (c.sl == 0) {
+        if (k.o_status) k.o_status[s] = R.status;
+        if (k.o_reason) k.o_reason[s] = R.reason;
+        if (k.o_iterations) k.o_iterations[s] = R.iter;
+        if (k.o_evaluations) k.o_evaluations[s] = R.evals;
+        if (k.o_initial_cost) k.o_initial_cost[s] = sv[S_INITIAL_COST];
+        if (k.o_final_cost) k.o_final_cost[s] = sv[S_COST];
+      }
+      if (k.o_params && c.sl < P) k.o_params[s * P + c.sl] = xc[c.sl];
+      // saving_velocities[i], i = 0..T: block i/bl for i < CH, else the last block (src/optimizer.cpp:390-411)
+      if (k.o_cmds) {
+        for (int i = c.sl; i <= T; i += W) {
+          const int b = (i < k.CH) ? i / k.bl : blast;
+          k.o_cmds[(s * (T + 1) + i) * 2] = xc[2 * b];
+          k.o_cmds[(s * (T + 1) + i) * 2 + 1] = xc[2 * b + 1];
+        }
+      }
+      if (k.o_path) {
+        // sequential re-roll with the reference's quaternion round trips (:420-446); slot-uniform, lane 0 stores
+        double px = c.x0, py = c.y0, yaw = yaw_roundtrip(c.yaw0);
+        for (int i = 0; i <= T; ++i) {
+          const int b = (i < k.CH) ? i / k.bl : blast;
+          const double v = xc[2 * b], w = xc[2 * b + 1];
+          double sn, cs;
+          sincos(yaw, &sn, &cs);
+          px = px + v * cs * k.dt;
+          py = py + v * sn * k.dt;
+          yaw = yaw_roundtrip(yaw + w * k.dt);
+          if (c.sl == 0) {
+            double* o = k.o_path + (s * (T + 1) + i) * 3;
+            o[0] = px; o[1] = py; o[2] = yaw;
+          }
+        }
+      }
+      R.phase = PH_FETCH;
+    }
   }
+}
+
+// K1 stand-alone: one sweep per scene at given parameters, rows written to HBM (parity checks, roofline runs).
+template <int NB, int W>
+__global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
+  constexpr int P = 2 * NB;
+  constexpr int S = kWave / W;
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / W;
+  Ctx c;
+  c.kp = &k;
+  c.sl = lane - slot * W;
+  c.L = make_layout(k.T, k.N, P, false);
+  c.lds = lds_all + (size_t)slot * c.L.total;
+  c.wave_lds = lds_all + (size_t)S * c.L.total;
+  c.slot = slot;
+  const int scene_raw = blockIdx.x * S + slot;
+  const bool live = scene_raw < k.B;
+  const int scene = live ? scene_raw : k.B - 1;
+  load_scene<W>(c, scene);
+  const size_t s = scene;
+  double* out_r = (live && k.e_residuals) ? k.e_residuals + s * k.e_M : nullptr;
+  double* out_J = (live && k.e_jacobian) ? k.e_jacobian + s * (size_t)k.e_M * P : nullptr;
+  if (!c.has_people) {  // rows a scene without people does not have stay zero
+    const int M5 = 5 * k.T + k.nfeas;
+    for (int i = M5 + c.sl; i < k.e_M; i += W) {
+      if (out_r) out_r[i] = 0.0;
+      if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)i * P + q] = 0.0;
+    }
+  }
+  const GramView G = sweep<NB, W>(c, k.e_x + s * P, out_r, out_J);
+  if (live && c.sl == 0 && k.e_cost) k.e_cost[s] = 0.5 * G(P, P);
+  if (live && k.e_gradient && c.sl < P) k.e_gradient[s * P + c.sl] = G(c.sl, P);
 }
 
 }  // namespace smpc

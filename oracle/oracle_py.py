@@ -29,6 +29,9 @@ def lib():
         _lib.smpc_oracle_solve_batch.restype = C.c_int
         _lib.smpc_oracle_solve_batch.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch),
                                                  C.POINTER(SmpcResultBatch), C.c_int]
+        _lib.smpc_oracle_solve_batch2.restype = C.c_int
+        _lib.smpc_oracle_solve_batch2.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch),
+                                                  C.POINTER(SmpcResultBatch), C.c_int, C.c_void_p]
         _lib.smpc_oracle_eval_batch.restype = C.c_int
         _lib.smpc_oracle_eval_batch.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch), C.c_void_p,
                                                 C.POINTER(SmpcEvalOut)]
@@ -38,8 +41,22 @@ def lib():
     return _lib
 
 
-def solve(params, scenes, nthreads=1):
+def set_theta_zero_convention(on: bool):
+    """False (default): reference-literal sign(theta). True: theta := 0 when both velocities are exactly equal
+    (the HIP path's convention; removes the libm-noise dependence of such scenes)."""
+    lib().smpc_oracle_set_option(1, 1 if on else 0)
+
+
+def solve(params, scenes, nthreads=1, theta_zero_convention=False):
     """Solve every scene with the CPU oracle. Returns a dict of numpy arrays (same fields as smpc_result_batch)."""
+    set_theta_zero_convention(theta_zero_convention)
+    try:
+        return _solve(params, scenes, nthreads)
+    finally:
+        set_theta_zero_convention(False)
+
+
+def _solve(params, scenes, nthreads=1):
     CH, bl, nb, P, M, _ = params.dims(scenes.T, True)
     B, T = scenes.B, scenes.T
     out = {
@@ -51,9 +68,13 @@ def solve(params, scenes, nthreads=1):
     for k, v in out.items():
         setattr(rb, k, v.ctypes.data)
     cp, sb = params.to_c(), scenes.to_c()
-    rc = lib().smpc_oracle_solve_batch(C.byref(cp), C.byref(sb), C.byref(rb), int(nthreads))
+    events = np.zeros(B, np.int32)
+    rc = lib().smpc_oracle_solve_batch2(C.byref(cp), C.byref(sb), C.byref(rb), int(nthreads), events.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"smpc_oracle_solve_batch failed: {rc}")
+    # diagnostic: evaluations whose sign(theta) was decided by libm rounding noise (robot stopped beside a standing
+    # person); the reference's own result is not reproducible across libm builds for such scenes
+    out["sign_noise_events"] = events
     return out
 
 

@@ -169,6 +169,18 @@ template <typename T> inline T WrapToPi(T angle) {
 
 template <typename T> struct Agent6 { T x, y, yaw, t, lv, av; };
 
+// Diagnostic only: number of social-force evaluations whose sign(theta) (:210) was decided by last-bit rounding
+// noise: both velocities equal (velDiff == 0 exactly, so theta is mathematically 0) yet theta came out non-zero
+// (and the force term it flips is not negligible, |fa| > 1e-10).
+// The reference's own result then depends on its libm / compiler; parity tests report and set such scenes aside.
+thread_local long g_sign_noise_events = 0;
+// Test-infrastructure option (smpc_oracle_set_option): 0 = reference-literal (default); 1 = when both velocities
+// are exactly equal take theta == 0 exactly instead of the libm-noise value. This is the convention the HIP path
+// uses (csrc/smpc_device.hpp social_force); with it the oracle is a noise-free checker for every scene.
+int g_opt_theta_zero_when_equal_velocities = 0;
+inline void ZeroValue(double& x) { x = 0.0; }
+inline void ZeroValue(Jet& x) { x.a = 0.0; }
+
 // a3  computeSocialForce (critics/social_work_cost_function.hpp:164-228); constants src/critics/social_work_cost_function.cpp:38-43
 template <typename T>
 Vec2<T> SocialForce(const Agent6<T>& me, const Agent6<T>* agents, int n_agents) {
@@ -187,10 +199,13 @@ Vec2<T> SocialForce(const Agent6<T>& me, const Agent6<T>* agents, int n_agents) 
     T interactionLength = Norm(iv);                                                         // :194
     Vec2<T> idir{iv.x / interactionLength, iv.y / interactionLength};                       // :195-196
     T theta = WrapToPi(Atan2(diffDirection.y, diffDirection.x) - Atan2(idir.y, idir.x));    // :198-200
+    const bool sign_is_noise = Value(velDiff.x) == 0.0 && Value(velDiff.y) == 0.0 && Value(theta) != 0.0;
+    if (sign_is_noise && g_opt_theta_zero_when_equal_velocities) ZeroValue(theta);
     T B = T(gamma) * interactionLength;                                                     // :203
     T fv = -Exp(-Norm(diff) / B - (T(nPrime) * B * theta) * (T(nPrime) * B * theta));       // :205-207
     T sign = (theta > 0.0) ? T(1.0) : T(-1.0);                                              // :210
     T fa = -sign * Exp(-Norm(diff) / B - (T(n) * B * theta) * (T(n) * B * theta));          // :212-215
+    if (sign_is_noise && std::fabs(Value(fa)) > 1e-10) ++g_sign_noise_events;  // diagnostic only
     Vec2<T> forceVelocity{fv * idir.x, fv * idir.y};                                        // :218
     Vec2<T> leftNormal{-idir.y, idir.x};                                                    // :220
     Vec2<T> forceAngle{fa * leftNormal.x, fa * leftNormal.y};                               // :222
@@ -686,6 +701,7 @@ struct TraceRow { double iter, cost, cost_change, gradient_max_norm, step_norm, 
 
 struct SolveResult {
   int status = SMPC_FAILURE, reason = SMPC_REASON_NONE, iterations = 0, evaluations = 0;
+  long sign_noise_events = 0;
   double initial_cost = 0.0, final_cost = 0.0;
   std::vector<double> x;
 };
@@ -710,6 +726,7 @@ class Minimizer {
   SolveResult Run(const double* x_init) {
     const smpc_params& prm = *s_.prm;
     SolveResult res;
+    const long events0 = g_sign_noise_events;
     x_.assign(x_init, x_init + P_);
     r_.assign(M_, 0.0); J_.assign(static_cast<size_t>(M_) * P_, 0.0); g_.assign(P_, 0.0); scale_.assign(P_, 1.0);
     std::vector<double> zero(P_, 0.0), cand(P_), delta(P_), step(P_);
@@ -826,6 +843,7 @@ class Minimizer {
     res.iterations = iteration_;
     res.x = best_x_;
     res.final_cost = minimum_cost;
+    res.sign_noise_events = g_sign_noise_events - events0;
     return res;
   }
 
@@ -1023,7 +1041,7 @@ bool MakeScene(const smpc_params* prm, const smpc_scene_batch* sb, int b, Scene*
   return s->d.nb <= SMPC_MAX_BLOCKS;
 }
 
-void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_result_batch* out, std::vector<TraceRow>* trace) {
+void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_result_batch* out, std::vector<TraceRow>* trace, int32_t* sign_events = nullptr) {
   Scene s;
   MakeScene(prm, sb, b, &s);
   const int P = s.d.P, T = s.d.T;
@@ -1039,6 +1057,7 @@ void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_re
   if (out->evaluations) out->evaluations[b] = r.evaluations;
   if (out->initial_cost) out->initial_cost[b] = r.initial_cost;
   if (out->final_cost) out->final_cost[b] = r.final_cost;
+  if (sign_events) sign_events[b] = static_cast<int32_t>(std::min<long>(r.sign_noise_events, 2147483647L));
 }
 
 }  // namespace
@@ -1052,14 +1071,22 @@ int smpc_oracle_dims(const smpc_params* p, int T, int has_people, int* CH, int* 
 }
 
 // Solve all scenes on `nthreads` host threads (one solve per thread at a time, like Ceres' default num_threads = 1).
+int smpc_oracle_solve_batch2(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads, int32_t* sign_noise_events);
+
 int smpc_oracle_solve_batch(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads) {
+  return smpc_oracle_solve_batch2(prm, sb, out, nthreads, nullptr);
+}
+
+// As above; additionally sign_noise_events[B] (may be null) = per-scene count of social-force evaluations whose
+// sign(theta) was decided by rounding noise (see g_sign_noise_events).
+int smpc_oracle_solve_batch2(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads, int32_t* sign_noise_events) {
   if (!prm || !sb || !out || sb->on_device) return SMPC_ERR_INVALID_ARG;
   Dims d0 = MakeDims(*prm, sb->T, sb->N, true);
   if (d0.nb > SMPC_MAX_BLOCKS) return SMPC_ERR_UNSUPPORTED;
   nthreads = std::max(1, std::min(nthreads, sb->B));
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) {
-    pool.emplace_back([=]() { for (int b = t; b < sb->B; b += nthreads) SolveOne(prm, sb, b, out, nullptr); });
+    pool.emplace_back([=]() { for (int b = t; b < sb->B; b += nthreads) SolveOne(prm, sb, b, out, nullptr, sign_noise_events); });
   }
   for (auto& th : pool) th.join();
   return SMPC_OK;
@@ -1085,6 +1112,12 @@ int smpc_oracle_eval_batch(const smpc_params* prm, const smpc_scene_batch* sb, c
     if (out->gradient) std::memcpy(out->gradient + static_cast<size_t>(b) * P, g.data(), sizeof(double) * P);
   }
   return SMPC_OK;
+}
+
+// key 1: theta := 0 when both velocities are exactly equal (see g_opt_theta_zero_when_equal_velocities).
+int smpc_oracle_set_option(int key, int value) {
+  if (key == 1) { g_opt_theta_zero_when_equal_velocities = value; return 0; }
+  return SMPC_ERR_INVALID_ARG;
 }
 
 // Per-iteration trace of one scene: rows of 9 doubles

@@ -69,6 +69,11 @@ def main():
         ro = O.solve(p, sc)
         for k, v in ro.items():
             out[f"oracle_{k}"] = v
+        # same oracle with theta := 0 for exactly equal velocities (the HIP path's convention; identical to the
+        # literal run wherever oracle_sign_noise_events == 0)
+        rz = O.solve(p, sc, theta_zero_convention=True)
+        for k, v in rz.items():
+            out[f"oraclez_{k}"] = v
         eo = O.evaluate(p, sc, sc.init_params)
         out["oracle_residuals"], out["oracle_jacobian"] = eo["residuals"], eo["jacobian"]
         scene_path = os.path.join(HERE, f"{name}_scenes.npz")

@@ -1,6 +1,14 @@
 """GPU parity tests proper (`-m gpu`): every call goes through the C ABI (libsmpc_hip.so); the CPU oracle and
 the committed golden fixtures are the checkers. Tolerance: max |delta cmd| <= 1e-5 on the optimised command
-sequence (BASELINE.json north_star), everything f64."""
+sequence (BASELINE.json north_star), everything f64.
+
+One documented convention: the reference's social force takes sign(theta) (critics/social_work_cost_function.hpp:210)
+of theta = atan2(dir) - atan2(interaction dir). When the two velocities are EXACTLY equal (robot command clamped to
+v = 0 beside a standing person) theta is mathematically 0 and the reference's value is its libm's last-bit noise, so
+its sign — hence the solve — is not reproducible even between two builds of the reference. The HIP path takes
+theta := 0 there. The oracle can be run reference-literal (default) or with that convention; it also counts the
+evaluations where the noise decided (`sign_noise_events`). Tests compare EVERY scene against the convention oracle,
+and the literal oracle on every scene it did not flag."""
 import numpy as np
 import pytest
 
@@ -44,6 +52,16 @@ def test_k1_rows_match_oracle(Solver, oracle, name):
     for x in (sc.init_params, sc.init_params + 0.05 * rng.standard_normal(sc.init_params.shape)):
         eo = oracle.evaluate(prm, sc, x)
         eg = s.evaluate(sc, x)
+        if name == "all_agents_invalid":
+            # No valid agent: the reference's dual-number proxemics row has NaN tangents (-max/d0^2 = -inf, inf*0),
+            # which makes Ceres reject the evaluation. Both sides must flag the same rows; finite entries must agree.
+            bad_o = ~np.isfinite(eo["jacobian"]).all(axis=2)
+            bad_g = ~np.isfinite(eg["jacobian"]).all(axis=2)
+            assert bad_o.any() and np.array_equal(bad_o, bad_g)
+            for key in ("residuals", "jacobian"):
+                m = np.isfinite(eo[key]) & np.isfinite(eg[key])
+                assert np.max(np.abs(eo[key][m] - eg[key][m]) / np.maximum(1.0, np.abs(eo[key][m]))) < JAC_RTOL
+            continue
         for key, tol in (("residuals", JAC_RTOL), ("jacobian", JAC_RTOL), ("gradient", 1e-8)):
             err = np.abs(eo[key] - eg[key]) / np.maximum(1.0, np.abs(eo[key]))
             assert np.max(err) < tol, (key, float(np.max(err)))
@@ -54,16 +72,21 @@ def test_k1_rows_match_oracle(Solver, oracle, name):
 def test_solve_matches_committed_golden(Solver, name):
     prm, sc, exp = load_golden(name)
     res = Solver(prm).solve(sc)
-    assert np.max(cmd_err(res["cmds"], exp["oracle_cmds"])) <= CMD_TOL
-    assert np.max(np.abs(res["params"] - exp["oracle_params"])) <= CMD_TOL
-    assert res["status"].tolist() == exp["oracle_status"].tolist()
-    assert res["iterations"].tolist() == exp["oracle_iterations"].tolist()
-    assert np.max(np.abs(res["path"][:, :, :2] - exp["oracle_path"][:, :, :2])) <= 1e-5
-    assert np.max(yaw_err(res["path"][:, :, 2], exp["oracle_path"][:, :, 2])) <= 1e-5
-    assert np.allclose(res["final_cost"], exp["oracle_final_cost"], rtol=1e-8)
-    # ... and against the independent Python restatement's optimum
+    # every scene against the oracle under the theta := 0 convention (see module docstring of this test)
+    assert np.max(cmd_err(res["cmds"], exp["oraclez_cmds"])) <= CMD_TOL
+    assert np.max(np.abs(res["params"] - exp["oraclez_params"])) <= CMD_TOL
+    assert res["status"].tolist() == exp["oraclez_status"].tolist()
+    assert res["iterations"].tolist() == exp["oraclez_iterations"].tolist()
+    assert np.max(np.abs(res["path"][:, :, :2] - exp["oraclez_path"][:, :, :2])) <= 1e-5
+    assert np.max(yaw_err(res["path"][:, :, 2], exp["oraclez_path"][:, :, 2])) <= 1e-5
+    assert np.allclose(res["final_cost"], exp["oraclez_final_cost"], rtol=1e-8)
+    # the reference-literal oracle on every scene whose sign(theta) never hung on libm noise
+    clean = exp["oracle_sign_noise_events"] == 0
+    assert np.max(cmd_err(res["cmds"][clean], exp["oracle_cmds"][clean]), initial=0.0) <= CMD_TOL
+    # ... and the independent Python restatement's optimum (literal semantics) on its clean scenes
     n = exp["pyref_x"].shape[0]
-    assert np.max(np.abs(res["params"][:n] - exp["pyref_x"])) <= CMD_TOL
+    cl = clean[:n]
+    assert np.max(np.abs(res["params"][:n][cl] - exp["pyref_x"][cl]), initial=0.0) <= CMD_TOL
 
 
 SOLVE_CASES = {
@@ -83,27 +106,29 @@ SOLVE_CASES = {
 def test_solve_matches_oracle_on_seeded_scenes(Solver, oracle, name):
     prm, kw = SOLVE_CASES[name]
     sc = make_scenes(prm, **kw)
-    ro = oracle.solve(prm, sc, nthreads=16)
     rg = Solver(prm).solve(sc)
-    err = cmd_err(rg["cmds"], ro["cmds"])
-    bad = err > CMD_TOL
-    # The reference objective is discontinuous (sign(theta) in the social force, critics/social_work_cost_function.hpp:210):
-    # a last-ulp libm difference can flip an accept/reject decision. Such scenes are counted,
-    # must stay rare, and must still land on an equally good local optimum.
-    assert bad.mean() <= 0.02, f"{bad.sum()}/{len(bad)} scenes beyond {CMD_TOL}"
-    ok = ~bad
-    assert np.array_equal(rg["status"][ok], ro["status"][ok])
-    assert np.array_equal(rg["iterations"][ok], ro["iterations"][ok])
-    assert np.max(np.abs(rg["path"][ok][:, :, :2] - ro["path"][ok][:, :, :2]), initial=0.0) <= 1e-5
-    if bad.any():
-        rel = (rg["final_cost"][bad] - ro["final_cost"][bad]) / ro["final_cost"][bad]
-        assert np.median(np.abs(rel)) < 0.05
+    # (1) EVERY scene against the oracle under the theta := 0 convention
+    rz = oracle.solve(prm, sc, nthreads=16, theta_zero_convention=True)
+    assert np.max(cmd_err(rg["cmds"], rz["cmds"])) <= CMD_TOL
+    assert np.array_equal(rg["status"], rz["status"])
+    assert np.array_equal(rg["iterations"], rz["iterations"])
+    assert np.max(np.abs(rg["path"][:, :, :2] - rz["path"][:, :, :2])) <= 1e-5
+    assert np.max(yaw_err(rg["path"][:, :, 2], rz["path"][:, :, 2])) <= 1e-5
+    assert np.allclose(rg["final_cost"], rz["final_cost"], rtol=1e-8)
+    # (2) the reference-literal oracle on every scene it did not flag as decided by libm rounding noise
+    ro = oracle.solve(prm, sc, nthreads=16)
+    clean = ro["sign_noise_events"] == 0
+    assert clean.mean() > 0.5
+    assert np.max(cmd_err(rg["cmds"][clean], ro["cmds"][clean])) <= CMD_TOL
+    assert np.array_equal(rg["iterations"][clean], ro["iterations"][clean])
 
 
-def test_moving_crowd_has_no_divergent_scene(Solver, oracle):
-    """Without standing agents the sign(theta) discontinuity is never hit at theta == 0: every scene must agree."""
+def test_moving_crowd_has_no_noisy_scene(Solver, oracle):
+    """Without standing agents sign(theta) is never evaluated at theta == 0: the literal oracle flags nothing and
+    every scene must agree."""
     sc = make_scenes(README, 512, 8, seed=301, standing_fraction=0.0)
     ro = oracle.solve(README, sc, nthreads=16)
+    assert np.all(ro["sign_noise_events"] == 0)
     rg = Solver(README).solve(sc)
     assert np.max(cmd_err(rg["cmds"], ro["cmds"])) <= CMD_TOL
     assert np.array_equal(rg["iterations"], ro["iterations"])
@@ -145,7 +170,7 @@ def test_edge_cases(Solver, oracle):
     s = Solver(prm)
     # B = 1 (the plugin's use) and B = 0 (empty batch)
     one = make_scenes(prm, 1, 3, n_valid=3, map_cells=80, seed=401)
-    assert np.max(cmd_err(s.solve(one)["cmds"], oracle.solve(prm, one)["cmds"])) <= CMD_TOL
+    assert np.max(cmd_err(s.solve(one)["cmds"], oracle.solve(prm, one, theta_zero_convention=True)["cmds"])) <= CMD_TOL
     empty = one.select(np.array([], dtype=np.int64))
     out = s.solve(empty)
     assert out["cmds"].shape[0] == 0
@@ -168,6 +193,17 @@ def test_edge_cases(Solver, oracle):
     too_long = make_scenes(prm, 1, 3, T=70, map_cells=40, seed=405)
     with pytest.raises(SmpcError):
         s.solve(too_long)
+
+
+def test_no_valid_agent_fails_like_the_reference(Solver, oracle):
+    """people present but every projected agent invalid (e.g. all dropped by project_people, src/optimizer.cpp:598-603):
+    Ceres rejects the initial evaluation -> FAILURE -> Optimizer::optimize returns false (src/optimizer.cpp:384-388)."""
+    sc = make_scenes(README, 8, 3, n_valid=0, map_cells=80, seed=108)
+    ro = oracle.solve(README, sc)
+    rg = Solver(README).solve(sc)
+    assert np.all(ro["status"] == 2) and np.all(rg["status"] == 2)
+    assert np.all(rg["reason"] == 7) and np.all(rg["iterations"] == 0)
+    assert np.array_equal(rg["params"], ro["params"])        # the projected start point is handed back
 
 
 def test_fixed_iteration_mode_runs_all_iterations(Solver):

@@ -22,7 +22,7 @@ def run(name, p, B, N, **kw):
         if np.max(dj/sj) > 1e-6:
             b, m, q = np.unravel_index(np.argmax(dj/sj), dj.shape)
             print("   worst J at scene", b, "row", m, "col", q, eo["jacobian"][b, m], eg["jacobian"][b, m], "r", eo["residuals"][b,m], eg["residuals"][b,m])
-    t = time.time(); ro = O.solve(p, sc, nthreads=8); to = time.time() - t
+    t = time.time(); ro = O.solve(p, sc, nthreads=8, theta_zero_convention=True); to = time.time() - t
     t = time.time(); rg = s.solve(sc); tg = time.time() - t
     dc = np.abs(ro["cmds"] - rg["cmds"]).reshape(B, -1).max(axis=1)
     print(f"[{name}] solve: oracle {to:.2f}s gpu(host-staged) {tg:.3f}s kernel {s.last_kernel_ms():.3f} ms")
