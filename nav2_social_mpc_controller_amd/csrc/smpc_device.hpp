@@ -23,6 +23,7 @@
 namespace smpc {
 
 constexpr int kWave = 64;
+constexpr double kNoTarget = 1e300;  // agent-angle tag: no steering target at this step
 constexpr int kSoc = 15;  // sum F(2), sum dF/d{x,y,th,v}(8), sum |G|^2 (1), sum d|G|^2/d{x,y,th,v} (4)
 
 struct KParams {
@@ -49,6 +50,8 @@ struct KParams {
   double* o_initial_cost;
   double* o_final_cost;
   int* queue;  // scene work queue (one int, zeroed before every solve launch)
+  double* ws_ag;  // solve kernel: staged people blocks, [grid * slots][4][N][T] (L2-resident workspace)
+  unsigned long long* stamps;  // diagnostic builds only (SMPC_STAMPS): per-wave cycle sums per phase, [grid][8]
   // eval (K1) inputs / outputs
   const double* e_x;
   double* e_residuals;
@@ -63,21 +66,29 @@ struct LdsLayout {
   int ag;       // [4][N][T]  px, py, wx, wy of people_proj[t+1]
   int valid;    // [T]        bit a set = agent a valid at step t (64-bit words)
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
+  int inc;      // [2][T]     per-step position increments of the current sweep
+  int cst;      // [8]        x0, y0, yaw0, goal_yaw, origin x, origin y, final point x, y
+  int lanec;    // [3][T]     per step: path point x, y (path_pts[t+1]) and agent-angle target (kNoTarget = none)
   int lm;       // LM vectors / matrices / scalars
   int gram;     // [(P+1)^2] Gram of the latest sweep (VALU back-end; the MFMA back-end uses the wave's result tile)
   int scratch;  // polynomial scratch
   int total;
 };
 
+// with_lm = true is the solve kernel: LM state in LDS, staged people block in the global workspace (keeps the LDS
+// footprint of a wave small enough for 3-4 waves per SIMD); false is the stand-alone K1 kernel: people block in LDS.
 __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, bool with_lm) {
   LdsLayout L;
   int o = 0;
-  L.ag = o; o += 4 * T * (N > 0 ? N : 1);
+  L.ag = o; if (!with_lm) o += 4 * T * (N > 0 ? N : 1);
   L.valid = o; o += T;
   L.cs = o; o += 2 * (T + 1);
+  L.inc = o; o += 2 * T;
+  L.cst = o; o += 8;
+  L.lanec = o; o += 3 * T;
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
-  L.scratch = o; if (with_lm) o += 96;
+  L.scratch = o; if (with_lm) o += 96;  // generic line-search interpolation fallback
   L.total = (o + 1) & ~1;
   return L;
 }
@@ -92,6 +103,15 @@ __host__ __device__ constexpr int tile_slot_stride(int W) { return W * tile_cols
 // doubles of wave-shared LDS behind the per-slot blocks: row tile + 16x16 result tile
 __host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
   return use_mfma(P, W) ? (kWave / W) * tile_slot_stride(W) + 256 : 0;
+}
+
+// The workgroup is ONE wavefront: LDS operations of a wave execute in program order, so cross-lane hand-offs through
+// LDS only need the compiler not to reorder them — no s_barrier and, importantly, no s_waitcnt vmcnt(0) that a
+// __syncthreads() would add (it would drain unrelated global loads / stores at every hand-off).
+__device__ inline void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 template <int W> __device__ inline double slot_sum(double v) {
@@ -223,22 +243,28 @@ __device__ inline void bicubic(const uint8_t* __restrict__ map, int size_x, int 
 // ------------------------------------------------------------------------------------------------
 // Per-slot scene context (registers; slot-uniform unless noted)
 // ------------------------------------------------------------------------------------------------
+// In-kernel phase stamps (diagnostic build -DSMPC_STAMPS only; the shipped kernel executes none of this).
+#ifdef SMPC_STAMPS
+#define SMPC_STAMP(ctx, phase) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); (ctx).acc[phase] += _t - (ctx).t_last; (ctx).t_last = _t; } while (0)
+#else
+#define SMPC_STAMP(ctx, phase) do { } while (0)
+#endif
+
 struct Ctx {
+#ifdef SMPC_STAMPS
+  unsigned long long t_last;
+  unsigned long long acc[8];
+#endif
   const KParams* kp;
   int scene;   // scene index of this slot
   int sl;      // lane within the slot = horizon step owned by this lane (per-lane)
-  bool has_people;
-  double x0, y0, yaw0, goal_yaw, ox, oy;
-  const uint8_t* map;
-  double* lds;  // this slot's LDS block
-  double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
   int slot;
+  bool has_people;
+  const uint8_t* map;
+  double* lds;       // this slot's LDS block (scene constants, cos/sin block, LM state live here)
+  double* ag;        // staged people block [4][N][T] of this slot (LDS in K1, global workspace in the solve kernel)
+  double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
   LdsLayout L;
-  // per-lane: agent-angle tag (a7) and path targets of step sl
-  bool aa_active;
-  double aa_target;
-  double tx, ty;  // path_pts[sl+1]
-  double gx, gy;  // final trajectorized point
 };
 
 // Gram matrix [J r]^T [J r], packed upper triangle over P+1 columns (column P is r).
@@ -281,24 +307,21 @@ __device__ inline void load_scene(Ctx& c, int scene) {
   const size_t s = scene;
   c.scene = scene;
   c.has_people = (N > 0) && (k.has_people ? k.has_people[s] != 0 : true);
-  c.x0 = k.pose0[3 * s];
-  c.y0 = k.pose0[3 * s + 1];
-  c.yaw0 = k.pose0[3 * s + 2];
-  c.goal_yaw = k.goal_yaw[s];
+  const double x0 = k.pose0[3 * s], y0 = k.pose0[3 * s + 1], yaw0 = k.pose0[3 * s + 2];
   const size_t cm = (size_t)k.size_x * k.size_y;
   c.map = k.costmap + (k.costmap_shared ? 0 : cm * s);
-  c.ox = k.costmap_origin[k.costmap_shared ? 0 : 2 * s];
-  c.oy = k.costmap_origin[k.costmap_shared ? 1 : 2 * s + 1];
   const double* path_pts = k.path_pts + s * (T + 1) * 2;
-  const int tl = min(sl, T - 1);
-  c.tx = path_pts[2 * (tl + 1)];
-  c.ty = path_pts[2 * (tl + 1) + 1];
-  c.gx = path_pts[2 * T];
-  c.gy = path_pts[2 * T + 1];
-  c.aa_active = false;
-  c.aa_target = 0.0;
+  double* cst = c.lds + c.L.cst;
+  cst[0] = x0; cst[1] = y0; cst[2] = yaw0;
+  cst[3] = k.goal_yaw[s];
+  cst[4] = k.costmap_origin[k.costmap_shared ? 0 : 2 * s];
+  cst[5] = k.costmap_origin[k.costmap_shared ? 1 : 2 * s + 1];
+  cst[6] = path_pts[2 * T];
+  cst[7] = path_pts[2 * T + 1];
+  double* lanec = c.lds + c.L.lanec;
+  double aa_target = kNoTarget;
   if (c.has_people) {
-    double* ag = c.lds + c.L.ag;
+    double* ag = c.ag;
     unsigned long long* vmask = reinterpret_cast<unsigned long long*>(c.lds + c.L.valid);
     const double* ppl = k.people + s * (size_t)(T + 1) * 6 * N;
     const int TN = T * N;
@@ -322,26 +345,31 @@ __device__ inline void load_scene(Ctx& c, int scene) {
       double best = INFINITY;
       for (int a = 0; a < N; ++a) {
         if (f[3 * N + a] != -1.0) m |= (1ull << a);  // social_work:175
-        const double ddx = f[a] - c.x0, ddy = f[N + a] - c.y0;
+        const double ddx = f[a] - x0, ddy = f[N + a] - y0;
         const double d2 = ddx * ddx + ddy * ddy;
         if (d2 < best && f[4 * N + a] > 0.05) { best = d2; closest = a; }
       }
       vmask[sl] = m;
       if (closest >= 0 && !(best > 4.0)) {
         const double ax = f[closest], ay = f[N + closest], ayaw = f[2 * N + closest];
-        const double agent_angle_initial = atan2(ay - c.y0, ax - c.x0);
-        const double hd = ayaw - c.yaw0;
+        const double agent_angle_initial = atan2(ay - y0, ax - x0);
+        const double hd = ayaw - yaw0;
         const double heading_diff = atan2(sin(hd), cos(hd));
-        const double rel0 = agent_angle_initial - c.yaw0;
+        const double rel0 = agent_angle_initial - yaw0;
         const double rel = atan2(sin(rel0), cos(rel0));
         const double kThr = M_PI / 6.0, kUp = 5 * M_PI / 6.0;
         if (heading_diff <= -kUp || heading_diff >= kThr) {
-          if (!(rel < 0.0)) { c.aa_active = true; c.aa_target = c.yaw0 + (-(M_PI / 6.0)); }
+          if (!(rel < 0.0)) aa_target = yaw0 + (-(M_PI / 6.0));
         } else {
-          if (!(rel > 0.0)) { c.aa_active = true; c.aa_target = c.yaw0 + (M_PI / 6.0); }
+          if (!(rel > 0.0)) aa_target = yaw0 + (M_PI / 6.0);
         }
       }
     }
+  }
+  if (sl < T) {
+    lanec[sl] = path_pts[2 * (sl + 1)];
+    lanec[T + sl] = path_pts[2 * (sl + 1) + 1];
+    lanec[2 * T + sl] = aa_target;
   }
 }
 
@@ -359,86 +387,76 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   const double dt = k.dt;
   double* cs_ = c.lds + c.L.cs;
   double* sn_ = cs_ + (T + 1);
+  const double* cst = c.lds + c.L.cst;
   const int blast = (CH - 1) / bl;
-  double x[P];
-#pragma unroll
-  for (int q = 0; q < P; ++q) x[q] = xp[q];
+  const int tl = min(sl, T - 1);
+  const int myb = (sl < CH) ? sl / bl : blast;  // block driving step sl
+  const double vb = xp[2 * myb], wb = xp[2 * myb + 1];
 
   // ---- a1 rollout, block-structured. theta_sl by sequential adds in the reference's order (:46-61).
-  double th = c.yaw0;
+  double th = cst[2];
   {
     int j = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int end = (b >= blast) ? ((b == blast) ? T : 0) : (b + 1) * bl;
-      const double wdt = x[2 * b + 1] * dt;
+      const int end = (b == NB - 1) ? T : (b + 1) * bl;
+      const double wdt = xp[2 * b + 1] * dt;
       for (; j < end; ++j) th += (j < sl) ? wdt : 0.0;
     }
   }
-  const int myb = (sl < CH) ? sl / bl : blast;  // block driving step sl
-  double vb = 0.0, wb = 0.0;
-#pragma unroll
-  for (int q = 0; q < NB; ++q) { vb = (q == myb) ? x[2 * q] : vb; wb = (q == myb) ? x[2 * q + 1] : wb; }
-  double sn, cs;
-  sincos(th, &sn, &cs);
-  if (sl <= T) { cs_[sl] = cs; sn_[sl] = sn; }
+  {
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    if (sl <= T) { cs_[sl] = cs; sn_[sl] = sn; }
+  }
   const double th1 = th + wb * dt;  // theta_{sl+1}: the same add the reference performs at step sl
-  __syncthreads();
-  // x, y of pose_{sl+1} (sequential sums over j <= sl) and the sensitivities S of that pose.
-  double X = c.x0, Y = c.y0;
-  double Sxv[NB], Syv[NB], Sxw[NB], Syw[NB], Sthw[NB];
+  wave_lds_fence();
+  SMPC_STAMP(c, 1);
+  // x, y of pose_{sl+1}: sequential sums over j <= sl in the reference's order. Lane j first publishes its own
+  // increments v_b(j) cos(theta_j) dt / v_b(j) sin(theta_j) dt (computed exactly as the reference rounds them),
+  // then every lane adds them up in index order, 8 LDS reads in flight at a time.
+  double* px_ = c.lds + c.L.inc;
+  double* py_ = px_ + T;
+  if (sl < T) {
+    px_[sl] = vb * cs_[sl] * dt;
+    py_[sl] = vb * sn_[sl] * dt;
+  }
+  wave_lds_fence();
+  double X = cst[0], Y = cst[1];
   {
     int j = 0;
+    for (; j + 8 <= T; j += 8) {
+      double ax[8], ay[8];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int start = b * bl;
-      const int end = (b >= blast) ? ((b == blast) ? T : 0) : (b + 1) * bl;
-      const double v = x[2 * b];
-      const double vdt = v * dt;
-      double aC = 0.0, aS = 0.0, aJC = 0.0, aJS = 0.0;
-      for (; j < end; ++j) {
-        const double cj = cs_[j], sj = sn_[j];
-        const bool on = j <= sl;
-        const double kk = (double)(j - start);
-        X += on ? v * cj * dt : 0.0;
-        Y += on ? v * sj * dt : 0.0;
-        aC += on ? cj : 0.0;
-        aS += on ? sj : 0.0;
-        aJC = on ? fma(kk, cj, aJC) : aJC;
-        aJS = on ? fma(kk, sj, aJS) : aJS;
-      }
-      Sxv[b] = dt * aC;
-      Syv[b] = dt * aS;
-      // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
-      Sxw[b] = -vdt * dt * aJS;
-      Syw[b] = vdt * dt * aJC;
+      for (int u = 0; u < 8; ++u) { ax[u] = px_[j + u]; ay[u] = py_[j + u]; }
 #pragma unroll
-      for (int q = 0; q < b; ++q) {
-        Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
-        Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
-      }
-      const int cnt = min(max(sl + 1 - start, 0), end - start);
-      Sthw[b] = dt * (double)max(cnt, 0);
+      for (int u = 0; u < 8; ++u) { const bool on = (j + u) <= sl; X += on ? ax[u] : 0.0; Y += on ? ay[u] : 0.0; }
     }
+    for (; j < T; ++j) { const bool on = j <= sl; X += on ? px_[j] : 0.0; Y += on ? py_[j] : 0.0; }
   }
   const int t1 = min(sl + 1, T);
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
 
+  SMPC_STAMP(c, 2);
   // ---- a3 social work + a4 proxemics: walk the agents of step sl
   double soc[kSoc];
 #pragma unroll
   for (int i = 0; i < kSoc; ++i) soc[i] = 0.0;
   double pbest = 1.7976931348623157e308, pdx = 0.0, pdy = 0.0;
   if (c.has_people) {
-    const double* ag = c.lds + c.L.ag;
+    const double* ag = c.ag;
     const unsigned long long* vmask = reinterpret_cast<const unsigned long long*>(c.lds + c.L.valid);
     const int TN = T * N;
-    const int tl = min(sl, T - 1);
     const unsigned long long vm = vmask[tl];
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
+    // software prefetch of the next agent's block entry (the block sits in L2 for the solve kernel)
+    double npx = ag[tl], npy = ag[TN + tl], nwx = ag[2 * TN + tl], nwy = ag[3 * TN + tl];
     for (int a = 0; a < N; ++a) {
-      const int q = a * T + tl;
-      const double apx = ag[q], apy = ag[TN + q], awx = ag[2 * TN + q], awy = ag[3 * TN + q];
+      const double apx = npx, apy = npy, awx = nwx, awy = nwy;
+      if (a + 1 < N) {
+        const int q = (a + 1) * T + tl;
+        npx = ag[q]; npy = ag[TN + q]; nwx = ag[2 * TN + q]; nwy = ag[3 * TN + q];
+      }
       const bool valid = (vm >> a) & 1ull;
       const double dx = X - apx, dy = Y - apy;
       const double d2 = dx * dx + dy * dy;
@@ -476,6 +494,42 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     }
   }
 
+  SMPC_STAMP(c, 3);
+  // ---- sensitivities S of pose_{sl+1} (after the agent loop: keeps them out of its register budget)
+  double Sxv[NB], Syv[NB], Sxw[NB], Syw[NB], Sthw[NB];
+  {
+    int j = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int start = b * bl;
+      const int end = (b == NB - 1) ? T : (b + 1) * bl;
+      const double vdt = xp[2 * b] * dt;
+      double aC = 0.0, aS = 0.0, aJC = 0.0, aJS = 0.0;
+      for (; j < end; ++j) {
+        const double cj = cs_[j], sj = sn_[j];
+        const bool on = j <= sl;
+        const double kk = (double)(j - start);
+        aC += on ? cj : 0.0;
+        aS += on ? sj : 0.0;
+        aJC = on ? fma(kk, cj, aJC) : aJC;
+        aJS = on ? fma(kk, sj, aJS) : aJS;
+      }
+      Sxv[b] = dt * aC;
+      Syv[b] = dt * aS;
+      // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
+      Sxw[b] = -vdt * dt * aJS;
+      Syw[b] = vdt * dt * aJC;
+#pragma unroll
+      for (int q = 0; q < b; ++q) {
+        Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
+        Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
+      }
+      const int cnt = min(max(sl + 1 - start, 0), end - start);
+      Sthw[b] = dt * (double)max(cnt, 0);
+    }
+  }
+
+  SMPC_STAMP(c, 4);
   // ---- per-step rows: state-space gradients (gx, gy, gth) + direct dv on block myb, pushed into the Gram
   constexpr bool kMfma = use_mfma(P, W);
   constexpr int kCols = tile_cols(W);
@@ -507,12 +561,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
       for (int q = 0; q < P; ++q) my_row[q] = live ? row[q] : 0.0;
       my_row[P] = live ? r : 0.0;
-      __syncthreads();
+      wave_lds_fence();
       for (int m = 0; m < n_mfma; ++m) {
         const double a = rd_base[m * 4 * kCols];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
       }
-      __syncthreads();
+      wave_lds_fence();
     } else {
       if (live) gram.add_row(row, r);
     }
@@ -539,8 +593,9 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     // a7 agent angle
     {
       double r = 0.0, gth = 0.0;
-      if (c.aa_active) {
-        const double ad = wrap_angle(th1 - c.aa_target);
+      const double aa_target = (c.lds + c.L.lanec)[2 * T + tl];
+      if (aa_target != kNoTarget) {
+        const double ad = wrap_angle(th1 - aa_target);
         r = w.agent_angle_w * (ad * ad);
         gth = w.agent_angle_w * 2.0 * ad;
       }
@@ -578,23 +633,24 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   }
   // a8 goal align
   {
-    const double a = wrap_angle(c.goal_yaw - th1);
+    const double a = wrap_angle(cst[3] - th1);
     emit(o5 + 1, lane_live, w.goal_align_w * a * a, 0.0, 0.0, -2.0 * w.goal_align_w * a, 0.0);
   }
   // a2 distance (path follow -> final point; path align -> point sl+1)
   {
-    const double ddx = X - c.gx, ddy = Y - c.gy, q2 = ddx * ddx + ddy * ddy;
+    const double ddx = X - cst[6], ddy = Y - cst[7], q2 = ddx * ddx + ddy * ddy;
     emit(o5 + 2, lane_live, w.distance_w * q2 * q2, 4.0 * w.distance_w * q2 * ddx, 4.0 * w.distance_w * q2 * ddy, 0.0, 0.0);
   }
   {
-    const double ddx = X - c.tx, ddy = Y - c.ty, q2 = ddx * ddx + ddy * ddy;
+    const double* lanec = c.lds + c.L.lanec;
+    const double ddx = X - lanec[tl], ddy = Y - lanec[T + tl], q2 = ddx * ddx + ddy * ddy;
     emit(o5 + 3, lane_live, w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
   }
   // a5 obstacle
   {
     const double fxp = X + 0.25 * c1, fyp = Y + 0.25 * s1;
     const double inv_res = 1.0 / k.resolution;
-    const double ic = (fxp - c.ox) / k.resolution, ir = (fyp - c.oy) / k.resolution;
+    const double ic = (fxp - cst[4]) / k.resolution, ir = (fyp - cst[5]) / k.resolution;
     double f, dfdr, dfdc;
     bicubic(c.map, k.size_x, k.size_y, ir, ic, f, dfdr, dfdc);
     const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
@@ -611,7 +667,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
     for (int q = 1; q < NB; ++q) {
       if (q == sl) {
-        const double lin = x[2 * q] - x[2 * q - 2], ang = x[2 * q + 1] - x[2 * q - 1];
+        const double lin = xp[2 * q] - xp[2 * q - 2], ang = xp[2 * q + 1] - xp[2 * q - 1];
         r = w.velocity_feasibility_w * lin * lin + w.velocity_feasibility_w * ang * ang;
         row[2 * q] = 2.0 * w.velocity_feasibility_w * lin;
         row[2 * q - 2] = -2.0 * w.velocity_feasibility_w * lin;
@@ -653,7 +709,8 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     view.base = gt;
     view.ld = Q;
   }
-  __syncthreads();  // Gram visible to every lane of the slot; the cos/sin block may be rewritten by the next sweep
+  wave_lds_fence();  // Gram visible to every lane of the slot; the cos/sin block may be rewritten by the next sweep
+  SMPC_STAMP(c, 5);
   return view;
 }
 

@@ -58,6 +58,8 @@ struct smpc_handle {
   hipEvent_t ev0, ev1;
   bool timed;
   int* queue;  // device-side scene queue head
+  double* ws_ag;  // staged-people workspace of the persistent solve kernel
+  size_t ws_ag_bytes;
 };
 
 namespace {
@@ -151,12 +153,42 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     if (grid > resident) grid = resident;
     k.queue = h->queue;
     SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
+    const size_t need = (size_t)grid * S * 4 * k.T * (k.N > 0 ? k.N : 1) * sizeof(double);
+    if (need > h->ws_ag_bytes) {  // grows on first use / on a larger shape only; reused by every later launch
+      SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (h->ws_ag) SMPC_HIP_CHECK(hipFree(h->ws_ag));
+      h->ws_ag = nullptr; h->ws_ag_bytes = 0;
+      SMPC_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws_ag), need));
+      h->ws_ag_bytes = need;
+    }
+    k.ws_ag = h->ws_ag;
+#ifdef SMPC_STAMPS
+    {  // diagnostic build: per-wave phase cycle sums, dumped to stderr after the launch
+      static unsigned long long* d_stamps = nullptr; static int cap = 0;
+      if (grid > cap) { if (d_stamps) (void)hipFree(d_stamps); SMPC_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_stamps), (size_t)grid * 8 * sizeof(unsigned long long))); cap = grid; }
+      k.stamps = d_stamps;
+    }
+#endif
   }
   SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(smpc::kWave), shmem, h->stream, k);
   SMPC_HIP_CHECK(hipGetLastError());
   SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
+#ifdef SMPC_STAMPS
+  if (!eval) {
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> hs((size_t)grid * 8);
+    SMPC_HIP_CHECK(hipMemcpy(hs.data(), k.stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double tot[8] = {0};
+    for (int g = 0; g < grid; ++g) for (int i = 0; i < 8; ++i) tot[i] += (double)hs[(size_t)g * 8 + i];
+    double all = 0; for (int i = 0; i < 8; ++i) all += tot[i];
+    static const char* names[8] = {"fetch+load_scene", "theta+sincos", "xy-loop", "agent-loop", "sens-loop", "rows+mfma+gram", "lm+output", "ls-interpolation"};
+    std::fprintf(stderr, "[stamps] grid=%d mean cycles/wave=%.0f:", grid, all / grid);
+    for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * tot[i] / all);
+    std::fprintf(stderr, "\n");
+  }
+#endif
   return SMPC_OK;
 }
 
@@ -236,6 +268,8 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
   h->stream = nullptr;
   h->timed = false;
   h->queue = nullptr;
+  h->ws_ag = nullptr;
+  h->ws_ag_bytes = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); delete h; return nullptr; }
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -249,6 +283,7 @@ void smpc_destroy(smpc_handle* h) {
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
   if (h->queue) (void)hipFree(h->queue);
+  if (h->ws_ag) (void)hipFree(h->ws_ag);
   delete h;
 }
 

@@ -271,12 +271,22 @@ template <int nc> __device__ inline double eval_poly_reg(const double (&p)[nc], 
 // Real parts of the 4 roots of a quartic q[0] x^4 + ... + q[4] (q[0] != 0): Aberth-Ehrlich with the four roots
 // iterated simultaneously on 4 neighbouring lanes (lane & 3 = root index), same start points and stopping rule
 // as poly_roots_real(). Returns all four real parts in every lane.
+// 1/x to ~1e-16 relative: hardware estimate + two Newton steps (only used where a last-bit error is harmless).
+__device__ inline double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * fma(-x, r, 2.0);
+  r = r * fma(-x, r, 2.0);
+  return r;
+}
+
 __device__ inline void quartic_roots_real_lanes(const double (&q)[5], double (&roots)[4]) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 3, base = lane & ~3;
   double cm[5];
+  const double inv_q0 = 1.0 / q[0];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) cm[i] = q[i] / q[0];
+  for (int i = 0; i < 5; ++i) cm[i] = q[i] * inv_q0;
+  cm[0] = 1.0;
   double radius = 0.0;
   radius = fmax(radius, fabs(cm[1]));
   radius = fmax(radius, sqrt(fabs(cm[2])));
@@ -286,6 +296,8 @@ __device__ inline void quartic_roots_real_lanes(const double (&q)[5], double (&r
   double sn, cs;
   sincos(2.0 * M_PI * r / 4 + 0.4, &sn, &cs);
   double zr = radius * cs, zi = radius * sn;
+  // The Aberth correction only has to vanish at a root (that is decided by the Horner value of the polynomial), so
+  // the reciprocals inside it use the fast form; the fixed point — the root — is unaffected.
   for (int it = 0; it < 200; ++it) {
     double pr = cm[0], pi = 0.0, dr = 0.0, di = 0.0;
 #pragma unroll
@@ -300,46 +312,51 @@ __device__ inline void quartic_roots_real_lanes(const double (&q)[5], double (&r
     for (int j = 0; j < 4; ++j) {
       const double ojr = __shfl(zr, base + j, 64), oji = __shfl(zi, base + j, 64);
       const double er = zr - ojr, ei = zi - oji;
-      const double ee = er * er + ei * ei;
-      if (j != r) { sr += er / ee; si += -ei / ee; }
+      const double inv_ee = fast_rcp(fmax(er * er + ei * ei, 1e-300));
+      if (j != r) { sr = fma(er, inv_ee, sr); si = fma(-ei, inv_ee, si); }
     }
-    double rel = 0.0;
+    double rel2 = 0.0;
     if (!(pr == 0.0 && pi == 0.0)) {
-      const double dd = dr * dr + di * di;
-      const double rr = (pr * dr + pi * di) / dd, ri = (pi * dr - pr * di) / dd;
+      const double inv_dd = fast_rcp(dr * dr + di * di);
+      const double rr = (pr * dr + pi * di) * inv_dd, ri = (pi * dr - pr * di) * inv_dd;
       const double qr = 1.0 - (rr * sr - ri * si), qi = -(rr * si + ri * sr);
-      const double qq = qr * qr + qi * qi;
-      const double str = (rr * qr + ri * qi) / qq, sti = (ri * qr - rr * qi) / qq;
+      const double inv_qq = fast_rcp(qr * qr + qi * qi);
+      const double str = (rr * qr + ri * qi) * inv_qq, sti = (ri * qr - rr * qi) * inv_qq;
       zr -= str; zi -= sti;
-      rel = sqrt(str * str + sti * sti) / fmax(1e-300, sqrt(zr * zr + zi * zi));
+      // |step| < 1e-15 |z|  <=>  |step|^2 < 1e-30 |z|^2
+      const double z2 = fmax(1e-300, zr * zr + zi * zi);
+      rel2 = (str * str + sti * sti) - 1e-30 * z2;  // > 0: not converged
     }
-    rel = fmax(rel, __shfl_xor(rel, 1, 64));
-    rel = fmax(rel, __shfl_xor(rel, 2, 64));
-    if (rel < 1e-15) break;
+    rel2 = fmax(rel2, __shfl_xor(rel2, 1, 64));
+    rel2 = fmax(rel2, __shfl_xor(rel2, 2, 64));
+    if (!(rel2 > 0.0)) break;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) roots[j] = __shfl(zr, base + j, 64);
 }
 
 // MinimizeInterpolatingPolynomial for the two common shapes: {lower, current} with all values and gradients valid
-// (cubic, nc = 4) and {lower, current, previous} (quintic, nc = 6). Returns false if the shape is not covered.
-__device__ __attribute__((noinline)) bool interpolate_step_fast(const Sample& lower, const Sample& previous, const Sample& current,
+// (cubic) and {lower, current, previous} (quintic). The lower bound sample always sits at x = 0, so its two
+// interpolation conditions fix the two lowest coefficients exactly (p(0) = f0, p'(0) = g0; in the full-pivot LU of
+// FindInterpolatingPolynomial those two unit rows are never touched by an elimination step either); the remaining
+// 2 / 4 coefficients come from the reduced system of the other samples. Returns false if the shape is not covered.
+__device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& previous, const Sample& current,
                                              double lo, double hi, double& step_size) {
   if (!(lower.value_valid && lower.gradient_valid && current.value_valid && current.gradient_valid)) return false;
+  if (lower.x != 0.0) return false;
   const bool use_prev = previous.value_valid;
   if (use_prev && !previous.gradient_valid) return false;
+  const double f0 = lower.value, g0 = lower.gradient;
   double opt_x = (lo + hi) / 2.0, opt_v;
   if (!use_prev) {
     constexpr int nc = 4;
-    double A[nc][nc], b[nc], poly[nc];
-    // rows: value(lower), gradient(lower), value(current), gradient(current); column j <-> x^(3-j)
-    const double x0 = lower.x, x1 = current.x;
-    A[0][3] = 1.0; A[0][2] = x0; A[0][1] = x0 * x0; A[0][0] = x0 * x0 * x0;
-    A[1][3] = 0.0; A[1][2] = 1.0; A[1][1] = 2.0 * x0; A[1][0] = 3.0 * (x0 * x0);
-    A[2][3] = 1.0; A[2][2] = x1; A[2][1] = x1 * x1; A[2][0] = x1 * x1 * x1;
-    A[3][3] = 0.0; A[3][2] = 1.0; A[3][1] = 2.0 * x1; A[3][0] = 3.0 * (x1 * x1);
-    b[0] = lower.value; b[1] = lower.gradient; b[2] = current.value; b[3] = current.gradient;
-    fullpiv_solve_reg<nc>(A, b, poly);
+    // a x^3 + b x^2 = f1 - g0 x1 - f0 ;  3 a x^2 + 2 b x = g1 - g0   (2 x 2, full pivoting)
+    const double x1 = current.x;
+    double A[2][2] = {{x1 * x1 * x1, x1 * x1}, {3.0 * (x1 * x1), 2.0 * x1}};
+    double b[2] = {current.value - g0 * x1 - f0, current.gradient - g0};
+    double ab[2];
+    fullpiv_solve_reg<2>(A, b, ab);
+    const double poly[nc] = {ab[0], ab[1], g0, f0};
     opt_v = eval_poly_reg<nc>(poly, opt_x);
     const double vlo = eval_poly_reg<nc>(poly, lo);
     if (vlo < opt_v) { opt_v = vlo; opt_x = lo; }
@@ -366,24 +383,21 @@ __device__ __attribute__((noinline)) bool interpolate_step_fast(const Sample& lo
     return true;
   }
   constexpr int nc = 6;
-  double A[nc][nc], b[nc], poly[nc];
-  const double xs[3] = {lower.x, current.x, previous.x};
-  const double vs[3] = {lower.value, current.value, previous.value};
-  const double gsv[3] = {lower.gradient, current.gradient, previous.gradient};
+  double A[4][4], b[4], hi4[4];
+  const double xs[2] = {current.x, previous.x};
+  const double vs[2] = {current.value, previous.value};
+  const double gsv[2] = {current.gradient, previous.gradient};
 #pragma unroll
-  for (int smp = 0; smp < 3; ++smp) {
+  for (int smp = 0; smp < 2; ++smp) {
     const double xv = xs[smp];
-    double pw = 1.0;
-#pragma unroll
-    for (int j = 5; j >= 0; --j) { A[2 * smp][j] = pw; pw *= xv; }
-    pw = 1.0;
-    A[2 * smp + 1][5] = 0.0;
-#pragma unroll
-    for (int j = 4; j >= 0; --j) { A[2 * smp + 1][j] = (5 - j) * pw; pw *= xv; }
-    b[2 * smp] = vs[smp];
-    b[2 * smp + 1] = gsv[smp];
+    const double x2 = xv * xv, x3 = x2 * xv, x4 = x2 * x2, x5 = x4 * xv;
+    A[2 * smp][0] = x5; A[2 * smp][1] = x4; A[2 * smp][2] = x3; A[2 * smp][3] = x2;
+    A[2 * smp + 1][0] = 5.0 * x4; A[2 * smp + 1][1] = 4.0 * x3; A[2 * smp + 1][2] = 3.0 * x2; A[2 * smp + 1][3] = 2.0 * xv;
+    b[2 * smp] = vs[smp] - g0 * xv - f0;
+    b[2 * smp + 1] = gsv[smp] - g0;
   }
-  fullpiv_solve_reg<nc>(A, b, poly);
+  fullpiv_solve_reg<4>(A, b, hi4);
+  const double poly[nc] = {hi4[0], hi4[1], hi4[2], hi4[3], g0, f0};
   double dq[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) dq[i] = (5 - i) * poly[i];
@@ -400,9 +414,10 @@ __device__ __attribute__((noinline)) bool interpolate_step_fast(const Sample& lo
     const double rt = roots[i];
     if (!(rt < lo || rt > hi)) { const double v = eval_poly_reg<nc>(poly, rt); if (v < opt_v) { opt_v = v; opt_x = rt; } }
   }
+  const double sx[3] = {lower.x, current.x, previous.x};
 #pragma unroll
   for (int smp = 0; smp < 3; ++smp) {
-    if (!(xs[smp] < lo || xs[smp] > hi)) { const double v = eval_poly_reg<nc>(poly, xs[smp]); if (v < opt_v) { opt_v = v; opt_x = xs[smp]; } }
+    if (!(sx[smp] < lo || sx[smp] > hi)) { const double v = eval_poly_reg<nc>(poly, sx[smp]); if (v < opt_v) { opt_v = v; opt_x = sx[smp]; } }
   }
   step_size = opt_x;
   return true;
@@ -411,7 +426,7 @@ __device__ __attribute__((noinline)) bool interpolate_step_fast(const Sample& lo
 // In-register Cholesky solve of (Hs + diag(D2)) y = gs for P <= 20 (fully unrolled, packed lower triangle).
 template <int P>
 __device__ inline bool cholesky_solve(const double* Hs, const double* D2, const double* gs, double (&y)[P]) {
-  double Lm[P * (P + 1) / 2];
+  double Lm[P * (P + 1) / 2], invd[P];
   auto li = [](int i, int j) { return i * (i + 1) / 2 + j; };  // j <= i
   bool ok = true;
 #pragma unroll
@@ -423,6 +438,7 @@ __device__ inline bool cholesky_solve(const double* Hs, const double* D2, const 
     const double l = sqrt(d);
     Lm[li(j, j)] = l;
     const double inv = 1.0 / l;
+    invd[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < P; ++i) {
       double v = Hs[i * P + j];
@@ -436,14 +452,14 @@ __device__ inline bool cholesky_solve(const double* Hs, const double* D2, const 
     double v = gs[i];
 #pragma unroll
     for (int kk = 0; kk < i; ++kk) v -= Lm[li(i, kk)] * y[kk];
-    y[i] = v / Lm[li(i, i)];
+    y[i] = v * invd[i];
   }
 #pragma unroll
   for (int i = P - 1; i >= 0; --i) {
     double v = y[i];
 #pragma unroll
     for (int kk = i + 1; kk < P; ++kk) v -= Lm[li(kk, i)] * y[kk];
-    y[i] = v / Lm[li(i, i)];
+    y[i] = v * invd[i];
   }
   return ok;
 }
@@ -469,8 +485,11 @@ struct LmRegs {  // slot-uniform integers / flags kept in registers
   bool step_successful, at_least_one, prev_vv, prev_gv, cur_vv, cur_gv;
 };
 
+#ifndef SMPC_SOLVE_MIN_WAVES
+#define SMPC_SOLVE_MIN_WAVES 2   // waves per SIMD the solve kernel's register allocation must allow
+#endif
 template <int NB, int W>
-__global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
+__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(const KParams k) {
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
   extern __shared__ double lds_all[];
@@ -483,6 +502,7 @@ __global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
   c.lds = lds_all + (size_t)slot * c.L.total;
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
+  c.ag = k.ws_ag + ((size_t)blockIdx.x * S + slot) * 4 * k.T * (k.N > 0 ? k.N : 1);
   const smpc_params& prm = k.prm;
   const int T = k.T;
   double* Hs = c.lds + c.L.lm;   // [P*P] scaled J^T J at the current point
@@ -504,8 +524,13 @@ __global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
   R.status = SMPC_NO_CONVERGENCE; R.reason = SMPC_REASON_MAX_ITERATIONS;
   R.step_successful = R.at_least_one = R.prev_vv = R.prev_gv = R.cur_vv = R.cur_gv = false;
   bool ever_loaded = false;
+#ifdef SMPC_STAMPS
+  for (int i = 0; i < 8; ++i) c.acc[i] = 0;
+  c.t_last = __builtin_amdgcn_s_memtime();
+#endif
 
   for (;;) {
+    SMPC_STAMP(c, 6);  // LM state machine + output stage of the previous trip
     // ---------------------------------------------------------------- fetch the next scene for idle slots
     if (R.phase == PH_FETCH) {
       int scene = 0;
@@ -537,6 +562,7 @@ __global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
       }
     }
     if (__all(R.phase == PH_IDLE)) break;
+    SMPC_STAMP(c, 0);  // fetch + load_scene
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
     const GramView GH = sweep<NB, W>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
@@ -628,8 +654,10 @@ __global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
           Sample lower{0.0, sv[S_COST], sv[S_GD0], true, true};
           Sample previous{sv[S_PREV_X], sv[S_PREV_V], sv[S_PREV_G], R.prev_vv, R.prev_gv};
           Sample current{alpha, val, gd, R.cur_vv, R.cur_gv};
+          SMPC_STAMP(c, 6);
           if (!interpolate_step_fast(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, step_size))
             step_size = interpolate_step(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, scratch);
+          SMPC_STAMP(c, 7);  // line-search interpolation
           failed = step_size * sv[S_DIRMAX] < 1e-9;
         }
         if (!failed) {
@@ -664,9 +692,10 @@ __global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
         R.step_successful = false;
         double step[P], D2[P];
         const double radius = sv[S_RADIUS];
+        const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-          const double d = sqrt(clampd(Hs[q * P + q], 1e-6, 1e32) / radius);
+          const double d = sqrt(clampd(Hs[q * P + q], 1e-6, 1e32) * inv_radius);
           D2[q] = d * d;
         }
         bool valid = cholesky_solve<P>(Hs, D2, gs, step);
@@ -732,25 +761,41 @@ __global__ __launch_bounds__(64, 2) void smpc_solve_kernel(const KParams k) {
         }
       }
       if (k.o_path) {
-        // sequential re-roll with the reference's quaternion round trips (:420-446); slot-uniform, lane 0 stores
-        double px = c.x0, py = c.y0, yaw = yaw_roundtrip(c.yaw0);
+        // Re-roll (:420-446). The reference round-trips every heading through a quaternion (setRPY / getYaw), which
+        // is the identity up to 1e-16 plus a wrap into (-pi, pi]; headings are produced here by the same sequential
+        // adds followed by an exact wrap, then lane i integrates... positions need the sequential sums of
+        // v cos(yaw_i) dt: lane i computes its own term, the running sum goes lane to lane in index order.
+        const double* cst = c.lds + c.L.cst;
+        double yaw = wrap_angle(cst[2]);
+        double my_yaw_in = yaw, my_yaw_out = yaw;
         for (int i = 0; i <= T; ++i) {
           const int b = (i < k.CH) ? i / k.bl : blast;
-          const double v = xc[2 * b], w = xc[2 * b + 1];
-          double sn, cs;
-          sincos(yaw, &sn, &cs);
-          px = px + v * cs * k.dt;
-          py = py + v * sn * k.dt;
-          yaw = yaw_roundtrip(yaw + w * k.dt);
-          if (c.sl == 0) {
-            double* o = k.o_path + (s * (T + 1) + i) * 3;
-            o[0] = px; o[1] = py; o[2] = yaw;
-          }
+          const double nyaw = wrap_angle(yaw + xc[2 * b + 1] * k.dt);
+          if (i == c.sl) { my_yaw_in = yaw; my_yaw_out = nyaw; }
+          yaw = nyaw;
+        }
+        const int bi = (c.sl < k.CH) ? c.sl / k.bl : blast;
+        double sn, cs;
+        sincos(my_yaw_in, &sn, &cs);
+        const double v = (c.sl <= T) ? xc[2 * min(bi, NB - 1)] : 0.0;
+        const double tx = v * cs * k.dt, ty = v * sn * k.dt;
+        double px = cst[0], py = cst[1], mx = 0.0, my = 0.0;
+        for (int i = 0; i <= T; ++i) {
+          px += __shfl(tx, slot * W + i, 64);
+          py += __shfl(ty, slot * W + i, 64);
+          if (i == c.sl) { mx = px; my = py; }
+        }
+        if (c.sl <= T) {
+          double* o = k.o_path + (s * (T + 1) + c.sl) * 3;
+          o[0] = mx; o[1] = my; o[2] = my_yaw_out;
         }
       }
       R.phase = PH_FETCH;
     }
   }
+#ifdef SMPC_STAMPS
+  if (k.stamps && lane == 0) for (int i = 0; i < 8; ++i) k.stamps[(size_t)blockIdx.x * 8 + i] = c.acc[i];
+#endif
 }
 
 // K1 stand-alone: one sweep per scene at given parameters, rows written to HBM (parity checks, roofline runs).
@@ -768,6 +813,7 @@ __global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
   c.lds = lds_all + (size_t)slot * c.L.total;
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
+  c.ag = c.lds + c.L.ag;
   const int scene_raw = blockIdx.x * S + slot;
   const bool live = scene_raw < k.B;
   const int scene = live ? scene_raw : k.B - 1;

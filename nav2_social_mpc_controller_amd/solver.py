@@ -17,7 +17,7 @@ from .params import OptimizerParams
 from .scenes import SceneBatch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmpc_hip.so")
+LIB_PATH = os.environ.get("SMPC_LIB_PATH", os.path.join(_HERE, "csrc", "libsmpc_hip.so"))  # env override: A/B builds
 _lib = None
 
 

@@ -31,7 +31,7 @@ def lib():
                                                  C.POINTER(SmpcResultBatch), C.c_int]
         _lib.smpc_oracle_solve_batch2.restype = C.c_int
         _lib.smpc_oracle_solve_batch2.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch),
-                                                  C.POINTER(SmpcResultBatch), C.c_int, C.c_void_p]
+                                                  C.POINTER(SmpcResultBatch), C.c_int, C.c_void_p, C.c_void_p]
         _lib.smpc_oracle_eval_batch.restype = C.c_int
         _lib.smpc_oracle_eval_batch.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch), C.c_void_p,
                                                 C.POINTER(SmpcEvalOut)]
@@ -69,12 +69,16 @@ def _solve(params, scenes, nthreads=1):
         setattr(rb, k, v.ctypes.data)
     cp, sb = params.to_c(), scenes.to_c()
     events = np.zeros(B, np.int32)
-    rc = lib().smpc_oracle_solve_batch2(C.byref(cp), C.byref(sb), C.byref(rb), int(nthreads), events.ctypes.data)
+    marginal = np.zeros(B, np.int32)
+    rc = lib().smpc_oracle_solve_batch2(C.byref(cp), C.byref(sb), C.byref(rb), int(nthreads), events.ctypes.data,
+                                        marginal.ctypes.data)
     if rc != 0:
         raise RuntimeError(f"smpc_oracle_solve_batch failed: {rc}")
     # diagnostic: evaluations whose sign(theta) was decided by libm rounding noise (robot stopped beside a standing
     # person); the reference's own result is not reproducible across libm builds for such scenes
     out["sign_noise_events"] = events
+    # diagnostic: accept / terminate / Armijo decisions taken with a margin below 1e-12 of the cost (rounding noise)
+    out["marginal_decisions"] = marginal
     return out
 
 

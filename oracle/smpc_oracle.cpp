@@ -178,6 +178,14 @@ thread_local long g_sign_noise_events = 0;
 // are exactly equal take theta == 0 exactly instead of the libm-noise value. This is the convention the HIP path
 // uses (csrc/smpc_device.hpp social_force); with it the oracle is a noise-free checker for every scene.
 int g_opt_theta_zero_when_equal_velocities = 0;
+// Diagnostic only: number of accept / terminate / Armijo decisions of a solve whose margin was below 1e-12 of the
+// cost, i.e. inside the rounding noise of summing ~300 squared residuals in a different order (SURVEY Appendix A.12:
+// "near an accept/reject or tolerance threshold a 1-ulp difference can flip a branch"). Parity tests report and set
+// such scenes aside; the reference's own path is not reproducible across builds there either.
+thread_local long g_marginal_decisions = 0;
+inline void NoteDecision(double lhs, double rhs, double cost_scale) {
+  if (std::fabs(lhs - rhs) <= 1e-12 * std::fabs(cost_scale)) ++g_marginal_decisions;
+}
 inline void ZeroValue(double& x) { x = 0.0; }
 inline void ZeroValue(Jet& x) { x.a = 0.0; }
 
@@ -582,6 +590,7 @@ bool FullPivSolve(std::vector<double> A, std::vector<double> b, int n, double* x
 // ------------------------------------------------------------------------------------------------
 // Polynomials (coefficients highest degree first), as used by the Armijo line search's interpolation.
 // ------------------------------------------------------------------------------------------------
+long g_aberth_calls = 0, g_aberth_iters = 0;  // diagnostics (single-threaded runs only)
 using Poly = std::vector<double>;
 inline double EvalPoly(const Poly& p, double x) { double v = 0.0; for (double c : p) v = v * x + c; return v; }
 Poly DiffPoly(const Poly& p) {
@@ -621,7 +630,9 @@ bool PolyRootsReal(Poly p, std::vector<double>* real) {
   radius = std::max(2.0 * radius, 1e-300);
   std::vector<C> z(deg);
   for (int i = 0; i < deg; ++i) z[i] = std::polar(radius, 2.0 * M_PI * i / deg + 0.4);
+  ++g_aberth_calls;
   for (int it = 0; it < 200; ++it) {
+    ++g_aberth_iters;
     double maxstep = 0.0;
     for (int i = 0; i < deg; ++i) {
       C pv = c[0], dv = 0.0;
@@ -701,7 +712,7 @@ struct TraceRow { double iter, cost, cost_change, gradient_max_norm, step_norm, 
 
 struct SolveResult {
   int status = SMPC_FAILURE, reason = SMPC_REASON_NONE, iterations = 0, evaluations = 0;
-  long sign_noise_events = 0;
+  long sign_noise_events = 0, marginal_decisions = 0;
   double initial_cost = 0.0, final_cost = 0.0;
   std::vector<double> x;
 };
@@ -726,7 +737,7 @@ class Minimizer {
   SolveResult Run(const double* x_init) {
     const smpc_params& prm = *s_.prm;
     SolveResult res;
-    const long events0 = g_sign_noise_events;
+    const long events0 = g_sign_noise_events, marg0 = g_marginal_decisions;
     x_.assign(x_init, x_init + P_);
     r_.assign(M_, 0.0); J_.assign(static_cast<size_t>(M_) * P_, 0.0); g_.assign(P_, 0.0); scale_.assign(P_, 1.0);
     std::vector<double> zero(P_, 0.0), cand(P_), delta(P_), step(P_);
@@ -818,6 +829,7 @@ class Minimizer {
       }
       // FunctionToleranceReached
       const double cost_change = cost_ - cand_cost;
+      if (tol_allowed) NoteDecision(std::fabs(cost_change), prm.fn_tol * cost_, cost_);
       if (tol_allowed && std::fabs(cost_change) <= prm.fn_tol * cost_) {
         res.status = SMPC_CONVERGENCE; res.reason = SMPC_REASON_FUNCTION_TOL;
         Trace(iteration_, cost_, cost_change, step_norm, 0.0, radius, ls_evals, 0);
@@ -827,6 +839,7 @@ class Minimizer {
       double rho;
       if (cand_cost >= std::numeric_limits<double>::max()) rho = std::numeric_limits<double>::lowest();
       else rho = (cost_ - cand_cost) / model_cost_change;
+      if (cand_cost < std::numeric_limits<double>::max()) NoteDecision(cost_ - cand_cost, 1e-3 * model_cost_change, cost_);
       if (rho > 1e-3) {
         // HandleSuccessfulStep
         x_ = cand; x_norm_ = Norm2(x_);
@@ -844,6 +857,7 @@ class Minimizer {
     res.x = best_x_;
     res.final_cost = minimum_cost;
     res.sign_noise_events = g_sign_noise_events - events0;
+    res.marginal_decisions = g_marginal_decisions - marg0;
     return res;
   }
 
@@ -958,6 +972,8 @@ class Minimizer {
     FunctionSample previous, current;
     LsEvaluate(*delta, 1.0, &current, res); ++*n_evals;
     int iters = 0;
+    auto note = [&]() { if (current.value_is_valid) NoteDecision(current.value, initial.value + sufficient_decrease * initial.gradient * current.x, initial.value); };
+    note();
     while (!current.value_is_valid || current.value > (initial.value + sufficient_decrease * initial.gradient * current.x)) {
       ++iters;
       if (iters >= max_iters) return;  // failure: delta unchanged
@@ -976,6 +992,7 @@ class Minimizer {
       if (step_size * dir_max < min_step_size) return;  // failure
       previous = current;
       LsEvaluate(*delta, step_size, &current, res); ++*n_evals;
+      note();
     }
     for (int q = 0; q < P_; ++q) (*delta)[q] *= current.x;
   }
@@ -1041,7 +1058,7 @@ bool MakeScene(const smpc_params* prm, const smpc_scene_batch* sb, int b, Scene*
   return s->d.nb <= SMPC_MAX_BLOCKS;
 }
 
-void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_result_batch* out, std::vector<TraceRow>* trace, int32_t* sign_events = nullptr) {
+void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_result_batch* out, std::vector<TraceRow>* trace, int32_t* sign_events = nullptr, int32_t* marginal = nullptr) {
   Scene s;
   MakeScene(prm, sb, b, &s);
   const int P = s.d.P, T = s.d.T;
@@ -1058,6 +1075,7 @@ void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_re
   if (out->initial_cost) out->initial_cost[b] = r.initial_cost;
   if (out->final_cost) out->final_cost[b] = r.final_cost;
   if (sign_events) sign_events[b] = static_cast<int32_t>(std::min<long>(r.sign_noise_events, 2147483647L));
+  if (marginal) marginal[b] = static_cast<int32_t>(std::min<long>(r.marginal_decisions, 2147483647L));
 }
 
 }  // namespace
@@ -1071,22 +1089,23 @@ int smpc_oracle_dims(const smpc_params* p, int T, int has_people, int* CH, int* 
 }
 
 // Solve all scenes on `nthreads` host threads (one solve per thread at a time, like Ceres' default num_threads = 1).
-int smpc_oracle_solve_batch2(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads, int32_t* sign_noise_events);
+int smpc_oracle_solve_batch2(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads, int32_t* sign_noise_events, int32_t* marginal_decisions);
 
 int smpc_oracle_solve_batch(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads) {
-  return smpc_oracle_solve_batch2(prm, sb, out, nthreads, nullptr);
+  return smpc_oracle_solve_batch2(prm, sb, out, nthreads, nullptr, nullptr);
 }
 
 // As above; additionally sign_noise_events[B] (may be null) = per-scene count of social-force evaluations whose
 // sign(theta) was decided by rounding noise (see g_sign_noise_events).
-int smpc_oracle_solve_batch2(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads, int32_t* sign_noise_events) {
+// marginal_decisions[B] (may be null) = per-scene count of decisions taken inside rounding noise (g_marginal_decisions).
+int smpc_oracle_solve_batch2(const smpc_params* prm, const smpc_scene_batch* sb, smpc_result_batch* out, int nthreads, int32_t* sign_noise_events, int32_t* marginal_decisions) {
   if (!prm || !sb || !out || sb->on_device) return SMPC_ERR_INVALID_ARG;
   Dims d0 = MakeDims(*prm, sb->T, sb->N, true);
   if (d0.nb > SMPC_MAX_BLOCKS) return SMPC_ERR_UNSUPPORTED;
   nthreads = std::max(1, std::min(nthreads, sb->B));
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) {
-    pool.emplace_back([=]() { for (int b = t; b < sb->B; b += nthreads) SolveOne(prm, sb, b, out, nullptr, sign_noise_events); });
+    pool.emplace_back([=]() { for (int b = t; b < sb->B; b += nthreads) SolveOne(prm, sb, b, out, nullptr, sign_noise_events, marginal_decisions); });
   }
   for (auto& th : pool) th.join();
   return SMPC_OK;
@@ -1113,6 +1132,9 @@ int smpc_oracle_eval_batch(const smpc_params* prm, const smpc_scene_batch* sb, c
   }
   return SMPC_OK;
 }
+
+// diagnostics of the polynomial root finder (single-threaded runs): out[0] = calls, out[1] = total iterations
+void smpc_oracle_aberth_stats(long* out) { out[0] = g_aberth_calls; out[1] = g_aberth_iters; }
 
 // key 1: theta := 0 when both velocities are exactly equal (see g_opt_theta_zero_when_equal_velocities).
 int smpc_oracle_set_option(int key, int value) {
