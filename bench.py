@@ -153,7 +153,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py as O
             cores = usable_cores()
-            n_sample = min(B, 32 * cores)
+            n_sample = min(B, 512 * cores)   # ~10-30 s of CPU work at ~35 solves/s/core
             sample = scenes.select(np.arange(n_sample))
             t1 = time.perf_counter()
             ref = O.solve(prm, sample, nthreads=cores)          # reference-literal oracle: the timed CPU baseline
