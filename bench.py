@@ -39,6 +39,33 @@ def usable_cores():
     return max(1, min(n, 64))
 
 
+def pmc_traffic_bytes(kernel="smpc_solve_kernel"):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN_pmc_summary.txt, made by
+    tools/profile_round.sh with separate --pmc passes): (FETCH_SIZE + WRITE_SIZE) KiB * 1024. The gfx950 x2
+    correction of FETCH_SIZE applies to 16 B/lane streaming reads only; this kernel reads 8 B/lane and byte gathers,
+    for which the counter is uncalibrated (MI355X_MICROARCH.md, HBM) — no correction applied. None if unavailable."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    if not files:
+        return None, None
+    fetch = write = None
+    active = False
+    for line in open(files[-1]):
+        if line.startswith("=="):
+            active = kernel in line
+        elif active:
+            m = re.match(r"\s*(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch\s+([0-9.e+]+)", line)
+            if m:
+                if m.group(1) == "FETCH_SIZE":
+                    fetch = float(m.group(2))
+                else:
+                    write = float(m.group(2))
+    if fetch is None or write is None:
+        return None, None
+    return (fetch + write) * 1024.0, os.path.basename(files[-1])
+
+
 def algorithmic_bytes_per_sweep(N, T, P, M):
     """every input read once, J and r written once, per scene per sweep."""
     return 8 * (6 * N * T + 2 * (T + 1) + P + 5) + 16 * T + 8 * (M * P + M)
@@ -131,6 +158,7 @@ def main():
         sweeps_per_launch = int(evals.sum())
         achieved = sweeps_per_launch * bytes_sweep / (solve_ms * 1e-3) / 1e9
         k1_achieved = B * bytes_sweep / (k1_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic_bytes()
         line = {
             "metric": "MPC solves/sec (horizon=18, 8 agents, 40 iters)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -146,7 +174,8 @@ def main():
                        "status": {"convergence": int(summ["converged"]), "no_convergence": int(summ["no_convergence"]),
                                   "failure": int(summ["failed"])}},
             "roofline": {"bound": "hbm", "kernel": "smpc_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": sweeps_per_launch * bytes_sweep,
                          "launch_ms": solve_ms, "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
                          "k1_sweep_kernel": {"launch_ms": k1_ms, "achieved": k1_achieved, "frac": k1_achieved / HBM_PEAK_GBS}},
         }
