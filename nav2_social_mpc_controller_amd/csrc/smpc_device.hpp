@@ -97,7 +97,11 @@ __host__ __device__ inline int slot_width(int T, int N) { return (T + 1 <= 32 &&
 
 // Gram contraction back-end: MFMA f64 16x16x4 when [J r] (P+1 columns) of every slot of the wave fits the 16
 // columns of one tile (two 32-lane slots -> 8 columns each), else plain VALU accumulation + shuffle reduction.
+#ifdef SMPC_FORCE_VALU_GRAM
+__host__ __device__ constexpr bool use_mfma(int, int) { return false; }
+#else
 __host__ __device__ constexpr bool use_mfma(int P, int W) { return (W == 32) ? (P + 1 <= 8) : (P + 1 <= 16); }
+#endif
 __host__ __device__ constexpr int tile_cols(int W) { return (W == 32) ? 8 : 16; }
 __host__ __device__ constexpr int tile_slot_stride(int W) { return W * tile_cols(W) + ((W == 32) ? 16 : 0); }  // +32 dwords: bank shift
 // doubles of wave-shared LDS behind the per-slot blocks: row tile + 16x16 result tile
@@ -149,21 +153,35 @@ struct Force {
 __device__ inline Force social_force(double dx, double dy, double ux, double uy) {
   const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, nn = 2.0, k = 2.1;
   Force R;
-  double n = sqrt(dx * dx + dy * dy);
-  const bool degenerate = n < 1e-6;  // :181-184  diff := (1e-6, 0), a constant: no dependence on positions
-  if (degenerate) { dx = 1e-6; dy = 0.0; n = 1e-6; }
-  const double inv_n = 1.0 / n;
+  double d2 = dx * dx + dy * dy;
+  const bool degenerate = d2 < 1e-12;  // |diff| < 1e-6 (:181-184): diff := (1e-6, 0), a constant: no dependence on positions
+  if (degenerate) { dx = 1e-6; dy = 0.0; d2 = 1e-12; }
+  const double inv_n = rsqrt(d2);
+  const double n = d2 * inv_n;
   const double ex = dx * inv_n, ey = dy * inv_n;  // diffDirection :185
   const double lux = lambda * ux, luy = lambda * uy;
   const double ivx = lux + ex, ivy = luy + ey;  // :191-192
-  const double L = sqrt(ivx * ivx + ivy * ivy);  // :194
-  const double inv_L = 1.0 / L;
+  const double L2 = ivx * ivx + ivy * ivy;
+  const double inv_L = rsqrt(L2);
+  const double L = L2 * inv_L;  // :194
   const double ix = ivx * inv_L, iy = ivy * inv_L;  // :195-196
-  // Equal velocities (robot stopped beside a standing person): theta is mathematically 0 and the reference's
-  // value is 0 up to the last-bit noise of its own libm (which then decides sign(theta), :210). Take exactly 0.
-  const double phi = (lux == 0.0 && luy == 0.0) ? 0.0 : wrap_to_pi(atan2(ey, ex) - atan2(iy, ix));  // :198-200
+  // theta = wrapToPi(atan2(dir) - atan2(idir)) (:198-200) is the angle from idir to dir = atan2(idir x dir, idir . dir).
+  // One atan2 instead of two wherever that cannot change sign(theta): away from theta = 0 and |theta| = pi
+  // (|sin theta| >= 1e-6). Closer than that the reference's own two-atan2 form is evaluated, so that the last-bit
+  // behaviour next to the discontinuity of sign(theta) (:210) stays the reference's.
+  // Equal velocities (robot stopped beside a standing person): theta is mathematically 0 and the reference's value is
+  // 0 up to the last-bit noise of its own libm (which then decides sign(theta)). Take exactly 0.
+  const double cross = ix * ey - iy * ex, dot = ix * ex + iy * ey;
+  double phi;
+  if (lux == 0.0 && luy == 0.0) {
+    phi = 0.0;
+  } else if (fabs(cross) >= 1e-6) {
+    phi = atan2(cross, dot);
+  } else {
+    phi = wrap_to_pi(atan2(ey, ex) - atan2(iy, ix));
+  }
   const double Bq = gamma * L;  // :203
-  const double inv_B = 1.0 / Bq;
+  const double inv_B = inv_L * (1.0 / gamma);
   const double a1 = nPrime * Bq * phi, a2 = nn * Bq * phi;
   const double base = -n * inv_B;
   const double E1 = exp(base - a1 * a1);  // :205-207
@@ -246,7 +264,9 @@ __device__ inline void bicubic(const uint8_t* __restrict__ map, int size_x, int 
 // In-kernel phase stamps (diagnostic build -DSMPC_STAMPS only; the shipped kernel executes none of this).
 #ifdef SMPC_STAMPS
 #define SMPC_STAMP(ctx, phase) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); (ctx).acc[phase] += _t - (ctx).t_last; (ctx).t_last = _t; } while (0)
+#define SMPC_STAMP2(ctx, phase) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); (ctx).acc2[phase] += _t - (ctx).t_last; (ctx).acc[5] += _t - (ctx).t_last; (ctx).t_last = _t; } while (0)
 #else
+#define SMPC_STAMP2(ctx, phase) do { } while (0)
 #define SMPC_STAMP(ctx, phase) do { } while (0)
 #endif
 
@@ -254,6 +274,7 @@ struct Ctx {
 #ifdef SMPC_STAMPS
   unsigned long long t_last;
   unsigned long long acc[8];
+  unsigned long long acc2[4];
 #endif
   const KParams* kp;
   int scene;   // scene index of this slot
@@ -451,6 +472,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
     // software prefetch of the next agent's block entry (the block sits in L2 for the solve kernel)
     double npx = ag[tl], npy = ag[TN + tl], nwx = ag[2 * TN + tl], nwy = ag[3 * TN + tl];
+#pragma unroll 2  // two agents per trip: measured +4% on the fused solve kernel (more independent work per wave)
     for (int a = 0; a < N; ++a) {
       const double apx = npx, apy = npy, awx = nwx, awy = nwy;
       if (a + 1 < N) {
@@ -555,17 +577,20 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   } else {
     gram.clear();
   }
-  const int n_mfma = (T + 3) / 4;
   auto push = [&](const double (&row)[P], double r, bool live) {
     if (kMfma) {
 #pragma unroll
       for (int q = 0; q < P; ++q) my_row[q] = live ? row[q] : 0.0;
       my_row[P] = live ? r : 0.0;
       wave_lds_fence();
-      for (int m = 0; m < n_mfma; ++m) {
-        const double a = rd_base[m * 4 * kCols];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-      }
+      // every lane of a slot writes its row (zeros beyond T), so all W/4 row groups are valid operands: issue the
+      // operand reads back to back, then the MFMA chain (an LDS round trip per MFMA would serialise ~200 cycles each)
+      constexpr int kM = W / 4;
+      double a[kM];
+#pragma unroll
+      for (int m = 0; m < kM; ++m) a[m] = rd_base[m * 4 * kCols];
+#pragma unroll
+      for (int m = 0; m < kM; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], a[m], acc, 0, 0, 0);
       wave_lds_fence();
     } else {
       if (live) gram.add_row(row, r);
@@ -624,6 +649,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       emit(2, live, r, gx, gy, 0.0, 0.0);
     }
   }
+  SMPC_STAMP2(c, 0);  // people critics (agent angle, social combine, proxemics) + their pushes
   const int o5 = people ? 3 : 0;
   // a6 velocity
   {
@@ -646,6 +672,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const double ddx = X - lanec[tl], ddy = Y - lanec[T + tl], q2 = ddx * ddx + ddy * ddy;
     emit(o5 + 3, lane_live, w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
   }
+  SMPC_STAMP2(c, 1);  // velocity, goal, 2 x distance
   // a5 obstacle
   {
     const double fxp = X + 0.25 * c1, fyp = Y + 0.25 * s1;
@@ -657,6 +684,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const double gth = w.obstacle_w * (dfdc * (-0.25 * s1) + dfdr * (0.25 * c1)) * inv_res;
     emit(o5 + 4, lane_live, w.obstacle_w * f, gx, gy, gth, 0.0);
   }
+  SMPC_STAMP2(c, 2);  // obstacle (bicubic gather)
   // a9 velocity feasibility between blocks sl and sl-1 (src/optimizer.cpp:364-370); the row follows step sl
   if (k.nfeas > 0) {
     const bool live = lane_live && sl >= 1 && sl <= k.nfeas;

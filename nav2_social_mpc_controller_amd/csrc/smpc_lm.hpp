@@ -526,6 +526,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   bool ever_loaded = false;
 #ifdef SMPC_STAMPS
   for (int i = 0; i < 8; ++i) c.acc[i] = 0;
+  for (int i = 0; i < 4; ++i) c.acc2[i] = 0;
   c.t_last = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -794,7 +795,10 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     }
   }
 #ifdef SMPC_STAMPS
-  if (k.stamps && lane == 0) for (int i = 0; i < 8; ++i) k.stamps[(size_t)blockIdx.x * 8 + i] = c.acc[i];
+  if (k.stamps && lane == 0) {
+    for (int i = 0; i < 8; ++i) k.stamps[(size_t)blockIdx.x * 12 + i] = c.acc[i];
+    for (int i = 0; i < 4; ++i) k.stamps[(size_t)blockIdx.x * 12 + 8 + i] = c.acc2[i];
+  }
 #endif
 }
 
