@@ -2,4 +2,8 @@
 # Builds libsmpc_hip.so (HIP kernels + C ABI) for gfx950, in-tree.
 set -euo pipefail
 cd "$(dirname "$0")"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o libsmpc_hip.so smpc_hip.hip "$@"
+# -disable-machine-licm: inside the persistent solve loop machine-LICM hoists dozens of 64-bit literals (libm polynomial
+# coefficients) and uniform kernel arguments out of the loop; they overflow the SGPR file, spill to VGPR lanes / scratch and
+# come back as v_readlane + scratch loads inside the sweep. Without it the solve kernel has no VGPR spills (241 VGPRs) and
+# runs 13% faster (measured, round 1).
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -disable-machine-licm -o libsmpc_hip.so smpc_hip.hip "$@"

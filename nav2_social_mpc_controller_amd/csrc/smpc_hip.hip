@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -149,6 +150,10 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     int per_cu = 0;
     SMPC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), smpc::kWave, shmem));
     if (per_cu < 1) per_cu = 1;
+    if (const char* cap = std::getenv("SMPC_MAX_WAVES_PER_CU")) {  // experiment knob: limit resident waves per CU
+      const int c = std::atoi(cap);
+      if (c >= 1 && c < per_cu) per_cu = c;
+    }
     const int resident = per_cu * h->num_cu;
     if (grid > resident) grid = resident;
     k.queue = h->queue;

@@ -435,9 +435,7 @@ __device__ inline bool cholesky_solve(const double* Hs, const double* D2, const 
 #pragma unroll
     for (int kk = 0; kk < j; ++kk) d -= Lm[li(j, kk)] * Lm[li(j, kk)];
     if (!(d > 0.0) || !isfinite(d)) ok = false;
-    const double l = sqrt(d);
-    Lm[li(j, j)] = l;
-    const double inv = 1.0 / l;
+    const double inv = rsqrt(d);  // 1 / l_jj; l_jj itself is never needed
     invd[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < P; ++i) {
@@ -696,8 +694,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-          const double d = sqrt(clampd(Hs[q * P + q], 1e-6, 1e32) * inv_radius);
-          D2[q] = d * d;
+          D2[q] = clampd(Hs[q * P + q], 1e-6, 1e32) * inv_radius;  // (sqrt(diag / radius))^2 of the LM strategy (A.6)
         }
         bool valid = cholesky_solve<P>(Hs, D2, gs, step);
         double mcc = 0.0;
