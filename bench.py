@@ -96,7 +96,10 @@ def main():
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        except TypeError:  # older torch: no device_id argument
+            dist.init_process_group("nccl")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
