@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--people", type=int, default=8)
     ap.add_argument("--fixed-iterations", type=int, default=0, help="1: run exactly 40 LM iterations per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="consecutive steps are issued round-robin on this many HIP streams (one solver handle each)")
     args = ap.parse_args()
 
     import numpy as np
@@ -110,11 +112,19 @@ def main():
     T = scenes.T
     CH, bl, nb, P, M, _ = prm.dims(T, True)
 
-    solver = BatchSolver(prm, device=local_rank)
-    stream = torch.cuda.Stream(device=device)
-    solver.set_stream(stream.cuda_stream)
+    # Consecutive steps (independent batches of a serving stream) are issued round-robin on a few HIP streams, one
+    # solver handle each: the persistent solve kernel ends with a tail of a few long scenes (per-scene LM iteration
+    # counts vary 5..40), and the next batch's waves fill the CUs that the tail leaves idle. Every step still solves
+    # the whole batch; results of step k land in result set k % streams.
+    n_streams = max(1, args.streams)
+    solvers = [BatchSolver(prm, device=local_rank) for _ in range(n_streams)]
+    hip_streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    for sv, st in zip(solvers, hip_streams):
+        sv.set_stream(st.cuda_stream)
+    solver = solvers[0]
     sb, tens = scenes.to_device(device)
-    rb, out = solver.alloc_results(B, T, device)
+    results = [sv.alloc_results(B, T, device) for sv in solvers]
+    rb, out = results[0]
     eo, eout = solver.alloc_eval(B, T, device)
 
     def barrier():
@@ -123,18 +133,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        solver.solve_device(sb, rb)
+    for w in range(max(args.warmup, n_streams)):
+        solvers[w % n_streams].solve_device(sb, results[w % n_streams][0])
     barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        solver.solve_device(sb, rb)
-        kernel_ms.append(None)   # duration read after the timed region (event pairs are per launch)
+    for k in range(args.steps):
+        solvers[k % n_streams].solve_device(sb, results[k % n_streams][0])
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-launch device time of the solve kernel, HIP events on the kernel's own stream (last launch)
-    solve_ms = solver.last_kernel_ms()
+    # per-launch device time of the solve kernel: HIP events around each handle's last launch, on its own stream
+    solve_ms_each = [sv.last_kernel_ms() for sv in solvers[:min(n_streams, args.steps)]]
+    solve_ms = float(sum(solve_ms_each) / len(solve_ms_each))
+    # an un-overlapped launch for reference (single stream, nothing else in flight)
+    solver.solve_device(sb, rb)
+    torch.cuda.synchronize(device)
+    solo_ms = solver.last_kernel_ms()
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -146,7 +159,7 @@ def main():
     status = out["status"].cpu().numpy()
     local = {"scenes": B, "sweeps": int(evals.sum()), "iterations": int(iters.sum()),
              "converged": int((status == 0).sum()), "no_convergence": int((status == 1).sum()),
-             "failed": int((status == 2).sum()), "max_solve_kernel_ms": solve_ms}
+             "failed": int((status == 2).sum()), "max_solve_kernel_ms": solve_ms, "max_solo_kernel_ms": solo_ms}
     summ = D.reduce_summary(local, device=device)
 
     # K1 stand-alone sweep (residual + Jacobian rows written to HBM) for the roofline line
@@ -159,7 +172,11 @@ def main():
         value = total_solves / elapsed_max
         bytes_sweep = algorithmic_bytes_per_sweep(N, T, P, M)
         sweeps_per_launch = int(evals.sum())
-        achieved = sweeps_per_launch * bytes_sweep / (solve_ms * 1e-3) / 1e9
+        # roofline of the solve kernel: one launch alone on the GPU (HIP events on its own stream, taken right after the
+        # timed region) — inside the timed region launches of consecutive steps overlap, their individual durations
+        # are not a per-kernel efficiency. The aggregate rate over the timed region is reported next to it.
+        achieved = sweeps_per_launch * bytes_sweep / (solo_ms * 1e-3) / 1e9
+        aggregate = args.steps * sweeps_per_launch * bytes_sweep / elapsed_max / 1e9
         k1_achieved = B * bytes_sweep / (k1_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic_bytes()
         line = {
@@ -171,7 +188,8 @@ def main():
                                    f"(T={T}, block=6, P={P}, M={M}), 200x200 u8 costmap per scene, DENSE_SCHUR, "
                                    f"max 40 LM iterations with Ceres termination rules"
                                    + (" DISABLED (fixed 40 iterations)" if args.fixed_iterations else ""),
-                       "scenes_per_gpu": B, "people": N, "T": T, "P": P, "M": M,
+                       "scenes_per_gpu": B, "people": N, "T": T, "P": P, "M": M, "streams": n_streams,
+                       "single_stream_solves_per_s_per_gpu": B / (summ["max_solo_kernel_ms"] * 1e-3),
                        "mean_lm_iterations": summ["iterations"] / summ["scenes"],
                        "mean_sweeps_per_solve": summ["sweeps"] / summ["scenes"],
                        "status": {"convergence": int(summ["converged"]), "no_convergence": int(summ["no_convergence"]),
@@ -179,7 +197,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "smpc_solve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": sweeps_per_launch * bytes_sweep,
-                         "launch_ms": solve_ms, "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
+                         "launch_ms": solo_ms, "launch_ms_overlapped_in_timed_region": solve_ms,
+                         "launch_note": "launch_ms = HIP-event duration of one solve launch alone on the GPU (what "
+                                        "`bench.py --streams 1` and the committed rocprofv3 kernel stats show); in the timed "
+                                        "region launches of consecutive steps overlap on %d streams" % n_streams,
+                         "aggregate_achieved_in_timed_region": aggregate, "aggregate_frac": aggregate / HBM_PEAK_GBS,
+                         "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
                          "k1_sweep_kernel": {"launch_ms": k1_ms, "achieved": k1_achieved, "frac": k1_achieved / HBM_PEAK_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
