@@ -42,6 +42,9 @@ EVAL_CASES = {
     "quirk_bl_not_dividing_ch": (README.replace(time_step=0.1), dict(B=32, N=3, seed=107)),
     "all_agents_invalid": (README, dict(B=16, N=3, n_valid=0, seed=108)),
     "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=16, N=5, seed=109)),
+    # T=28 (two scenes per wave) with 5 parameter blocks: [J r] has 11 columns -> VALU Gram back-end instead of MFMA
+    "w32_five_blocks_valu_gram": (README.replace(parameter_block_length=4), dict(B=32, N=6, seed=110)),
+    "six_blocks": (README.replace(parameter_block_length=3), dict(B=16, N=4, seed=111)),
 }
 
 
@@ -103,6 +106,7 @@ SOLVE_CASES = {
                          dict(B=128, N=3, seed=206, people_present=False)),
     "quirk_bl_not_dividing_ch": (README.replace(time_step=0.1), dict(B=128, N=3, seed=207)),
     "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=64, N=5, seed=209)),
+    "w32_five_blocks_valu_gram": (README.replace(parameter_block_length=4), dict(B=128, N=6, seed=210)),
 }
 
 
