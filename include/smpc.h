@@ -144,6 +144,31 @@ typedef struct smpc_eval_batch_out {
   double* gradient;  /* [B][P] J^T r */
 } smpc_eval_batch_out;
 
+/* People projection that feeds the hot path: Optimizer::project_people + computeObstacle
+ * (src/optimizer.cpp:554-728) with the Social Force Model of sfm.hpp, for B scenes at once. */
+typedef struct smpc_projection_batch {
+  int32_t B;
+  int32_t T;         /* robot_path has T+1 states; T projection steps */
+  int32_t N;         /* agents per scene (reference: 3 after people_to_status) */
+  int32_t on_device; /* 0: host pointers, 1: device pointers (outputs follow) */
+  float max_time;    /* naive_goal_time = trajectorizer.max_time (src/optimizer.cpp:558) */
+  float time_step;   /* the float the reference passes down (optimizer.hpp:170) */
+  const double* init_people; /* [B][N][6]    people_to_status output: x,y,yaw,t,lv,av; t == -1 marks invalid */
+  const double* robot_path;  /* [B][T+1][6]  format_to_optimize output (optim_status) */
+  const uint32_t* od_indexes; /* [B or 1][od_height][od_width] ObstacleDistance.indexes */
+  int32_t od_shared;          /* 1: one distance grid (and origin) for all scenes */
+  int32_t od_width, od_height;
+  float od_resolution;
+  const double* od_origin;    /* [B or 1][2] ObstacleDistance.info.origin.position.{x,y} */
+} smpc_projection_batch;
+
+/* per-scene outcome of smpc_project_people_batch: where the reference would throw std::runtime_error */
+enum smpc_projection_error {
+  SMPC_PROJ_OK = 0,
+  SMPC_PROJ_CELL_OUT_OF_BOUNDS = 1,  /* src/optimizer.cpp:693-700 */
+  SMPC_PROJ_INDEX_OUT_OF_BOUNDS = 2  /* :707-713 */
+};
+
 typedef struct smpc_handle smpc_handle;
 
 /* Problem dimensions implied by (params, T, has_people): fills any non-NULL output. Returns smpc_error. */
@@ -166,6 +191,12 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* scenes, smpc_result
 /* Evaluate residuals / Jacobian at `params` ([B][P], same memory space) — kernel K1 alone. */
 int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* scenes, const double* params,
                     smpc_eval_batch_out* out);
+
+/* Roll the people forward with the Social Force Model: people_proj [B][T+1][6][N] (the layout smpc_scene_batch.people
+ * expects; entry 0 = init_people, valid agents compacted to the front, the rest padded with t = -1 like the reference),
+ * error [B] (enum smpc_projection_error; may be NULL). Returns SMPC_ERR_INVALID_ARG for an empty / malformed grid
+ * (the reference throws, src/optimizer.cpp:676-687). */
+int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, double* people_proj, int32_t* error);
 
 /* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
  * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */

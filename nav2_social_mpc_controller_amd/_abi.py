@@ -77,6 +77,25 @@ class SmpcSceneBatch(C.Structure):
     ]
 
 
+class SmpcProjectionBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("T", C.c_int32),
+        ("N", C.c_int32),
+        ("on_device", C.c_int32),
+        ("max_time", C.c_float),
+        ("time_step", C.c_float),
+        ("init_people", C.c_void_p),
+        ("robot_path", C.c_void_p),
+        ("od_indexes", C.c_void_p),
+        ("od_shared", C.c_int32),
+        ("od_width", C.c_int32),
+        ("od_height", C.c_int32),
+        ("od_resolution", C.c_float),
+        ("od_origin", C.c_void_p),
+    ]
+
+
 class SmpcResultBatch(C.Structure):
     _fields_ = [
         ("params", C.c_void_p),
@@ -109,6 +128,7 @@ EXPORTED_SYMBOLS = [
     "smpc_set_stream",
     "smpc_solve_batch",
     "smpc_eval_batch",
+    "smpc_project_people_batch",
     "smpc_last_kernel_ms",
     "smpc_last_error",
     "smpc_abi_version",

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "smpc_lm.hpp"
+#include "smpc_project.hpp"
 
 // ================================================================================================
 // Host side of the C ABI
@@ -342,6 +343,55 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   SMPC_TRY(down(out->initial_cost, k.o_initial_cost, B, h->stream));
   SMPC_TRY(down(out->final_cost, k.o_final_cost, B, h->stream));
   SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SMPC_OK;
+}
+
+int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, double* people_proj, int32_t* error) {
+  if (!h || !in || !people_proj) { set_error("null handle / input / output"); return SMPC_ERR_INVALID_ARG; }
+  if (in->B < 0 || in->T < 1 || in->N < 1) { set_error("bad B/T/N"); return SMPC_ERR_INVALID_ARG; }
+  if (in->N + 1 > smpc::kWave) { set_error("N + 1 > 64 agents is not supported"); return SMPC_ERR_UNSUPPORTED; }
+  if (!in->init_people || !in->robot_path || !in->od_origin) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
+  // the reference throws for an empty / malformed ObstacleDistance grid (src/optimizer.cpp:676-687)
+  if (!in->od_indexes) { set_error("ObstacleDistance grid is empty"); return SMPC_ERR_INVALID_ARG; }
+  if (in->od_width <= 0 || in->od_height <= 0) { set_error("ObstacleDistance grid has invalid size"); return SMPC_ERR_INVALID_ARG; }
+  if (!(in->od_resolution > 0.0f)) { set_error("ObstacleDistance grid has invalid resolution"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  smpc::ProjParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = in->B; p.T = in->T; p.N = in->N;
+  int G = 2;
+  while (G < in->N + 1) G *= 2;
+  p.G = G;
+  p.max_time = in->max_time; p.time_step = in->time_step; p.od_resolution = in->od_resolution;
+  p.od_shared = in->od_shared; p.od_width = in->od_width; p.od_height = in->od_height;
+  const size_t B = in->B, T = in->T, N = in->N;
+  const size_t ngrid = in->od_shared ? 1 : B;
+  Staging st;
+  if (in->on_device) {
+    p.init_people = in->init_people; p.robot_path = in->robot_path; p.od_indexes = in->od_indexes; p.od_origin = in->od_origin;
+    p.people_proj = people_proj; p.error = error;
+  } else {
+    SMPC_TRY(st.up(in->init_people, B * N * 6, &p.init_people, h->stream));
+    SMPC_TRY(st.up(in->robot_path, B * (T + 1) * 6, &p.robot_path, h->stream));
+    SMPC_TRY(st.up(in->od_indexes, ngrid * (size_t)in->od_width * in->od_height, &p.od_indexes, h->stream));
+    SMPC_TRY(st.up(in->od_origin, ngrid * 2, &p.od_origin, h->stream));
+    SMPC_TRY(st.out(people_proj, B * (T + 1) * 6 * N, &p.people_proj));
+    SMPC_TRY(st.out(error, B, &p.error));
+  }
+  if (B > 0) {
+    const int per_wave = smpc::kWave / G;
+    const int grid = (int)((B + per_wave - 1) / per_wave);
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_project_kernel, dim3(grid), dim3(smpc::kWave), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!in->on_device) {
+    SMPC_TRY(down(people_proj, p.people_proj, B * (T + 1) * 6 * N, h->stream));
+    SMPC_TRY(down(error, p.error, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
   return SMPC_OK;
 }
 

@@ -1,0 +1,190 @@
+// smpc_project.hpp — batched people projection: Optimizer::project_people + computeObstacle
+// (reference src/optimizer.cpp:554-728) with the Social Force Model of include/nav2_social_mpc_controller/sfm.hpp
+// (computeForces :462-485 = desired + obstacle + social force, group forces identically zero here; updatePosition
+// :525-551). One lane per agent (the robot is the last lane of the group), G = next power of two >= N+1 lanes per
+// scene, 64/G scenes per wavefront; other agents' states travel by wavefront shuffles; the T steps are sequential.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/smpc.h"
+
+namespace smpc {
+
+struct ProjParams {
+  int B, T, N, G;
+  float max_time, time_step, od_resolution;
+  int od_shared, od_width, od_height;
+  const double* init_people;
+  const double* robot_path;
+  const uint32_t* od_indexes;
+  const double* od_origin;
+  double* people_proj;
+  int32_t* error;
+};
+
+__device__ inline double proj_wrap(double a) {
+  while (a <= -M_PI) a += 2 * M_PI;
+  while (a > M_PI) a -= 2 * M_PI;
+  return a;
+}
+
+// computeObstacle (src/optimizer.cpp:673-728): nearest-obstacle lookup, float arithmetic as in the reference;
+// returns agent - obstacle (the reference stores this DIFFERENCE where the SFM expects a position).
+__device__ inline int proj_obstacle(const ProjParams& p, const uint32_t* idx, double ox, double oy, double px, double py,
+                                    double& dx, double& dy) {
+  const double res = (double)p.od_resolution;
+  const unsigned int xcell = (unsigned int)(long long)floor((px - ox) / res);
+  const unsigned int ycell = (unsigned int)(long long)floor((py - oy) / res);
+  if (xcell >= (unsigned int)p.od_width || ycell >= (unsigned int)p.od_height) return SMPC_PROJ_CELL_OUT_OF_BOUNDS;
+  const unsigned int ob = idx[xcell + ycell * (unsigned int)p.od_width];
+  if (ob >= (unsigned int)p.od_width * (unsigned int)p.od_height) return SMPC_PROJ_INDEX_OUT_OF_BOUNDS;
+  const unsigned int oyc = ob / (unsigned int)p.od_width, oxc = ob % (unsigned int)p.od_width;
+  const float x = (float)((double)((float)oxc * p.od_resolution) + ox);
+  const float y = (float)((double)((float)oyc * p.od_resolution) + oy);
+  dx = px - (double)x;
+  dy = py - (double)y;
+  return SMPC_PROJ_OK;
+}
+
+__global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
+  const int lane = threadIdx.x & 63;
+  const int G = p.G, T = p.T, N = p.N;
+  const int grp = lane / G, g = lane - grp * G, base = grp * G;
+  const int scene_raw = blockIdx.x * (64 / G) + grp;
+  const bool live_scene = scene_raw < p.B;
+  const size_t s = live_scene ? scene_raw : p.B - 1;
+  const double* init = p.init_people + s * (size_t)N * 6;
+  const double* rpath = p.robot_path + s * (size_t)(T + 1) * 6;
+  const uint32_t* idx = p.od_indexes + (p.od_shared ? 0 : s * (size_t)p.od_width * p.od_height);
+  const double ox = p.od_origin[p.od_shared ? 0 : 2 * s], oy = p.od_origin[p.od_shared ? 1 : 2 * s + 1];
+  double* out = p.people_proj + s * (size_t)(T + 1) * 6 * N;
+  const double dt = (double)p.time_step;
+  const bool grid_not_valid = (p.od_width == 100 && p.od_height == 100);  // src/optimizer.cpp:598-603
+  const double kFd = 2.0, kFo = 20.0, kSig = 0.2, kFs = 2.1, kLam = 2.0, kGam = 0.35, kN = 2.0, kNp = 3.0, kRelax = 0.5;
+
+  // people_traj[0] = init_people
+  if (live_scene)
+    for (int q = g; q < N * 6; q += G) { const int a = q / 6, f = q - a * 6; out[(size_t)f * N + a] = init[a * 6 + f]; }
+
+  // compact the valid agents: lane g holds the g-th valid one; lane n_valid holds the robot
+  int n_valid = 0, src = -1;
+  for (int i = 0; i < N; ++i) {
+    if (init[i * 6 + 3] == -1.0 || grid_not_valid) continue;
+    if (n_valid == g) src = i;
+    ++n_valid;
+  }
+  const bool is_agent = g < n_valid;
+  const bool is_robot = g == n_valid;
+  const int n_act = n_valid + 1;
+  double px = 0, py = 0, vx = 0, vy = 0, yaw = 0, lv = 0, av = 0, des = 0.6, radius = 0.5;
+  double gx = 0, gy = 0, grad = 0.25, obx = 0, oby = 0;
+  bool has_goal = false;
+  int err = SMPC_PROJ_OK;
+  if (is_agent) {
+    px = init[src * 6]; py = init[src * 6 + 1]; yaw = init[src * 6 + 2]; lv = init[src * 6 + 4]; av = init[src * 6 + 5];
+    double sn, cs;
+    sincos(yaw, &sn, &cs);
+    vx = lv * cs; vy = lv * sn;
+    des = 0.5; radius = 0.5;
+    gx = px + (double)p.max_time * vx; gy = py + (double)p.max_time * vy; has_goal = true;  // constant-velocity goal :588-592
+    const int e = proj_obstacle(p, idx, ox, oy, px, py, obx, oby);
+    if (e) err = e;
+  }
+  for (int i = 0; i < T; ++i) {
+    if (is_robot) {  // the robot re-enters from the initial trajectory every step (:613-630)
+      const double* r = rpath + (size_t)i * 6;
+      px = r[0]; py = r[1]; yaw = r[2]; lv = r[4]; av = r[5];
+      double sn, cs;
+      sincos(yaw, &sn, &cs);
+      vx = lv * cs; vy = lv * sn;
+      des = 0.6; radius = 0.5;
+      gx = rpath[(size_t)T * 6]; gy = rpath[(size_t)T * 6 + 1]; has_goal = true;
+    }
+    // ---- computeForces (sfm.hpp:462-485)
+    double fx, fy;
+    {
+      const double ddx = gx - px, ddy = gy - py;
+      const double dn = sqrt(ddx * ddx + ddy * ddy);
+      if (has_goal && dn > grad) {  // computeDesiredForce :188-205
+        const double z = ddx * ddx + ddy * ddy;
+        const double ux = z > 0 ? ddx / sqrt(z) : ddx, uy = z > 0 ? ddy / sqrt(z) : ddy;
+        fx = kFd * (ux * des - vx) / kRelax;
+        fy = kFd * (uy * des - vy) / kRelax;
+      } else {
+        fx = -vx / kRelax;
+        fy = -vy / kRelax;
+      }
+    }
+    if (is_agent) {  // computeObstacleForce :207-235, one obstacle entry, used as a POSITION
+      const double mx = px - obx, my = py - oby;
+      const double z = mx * mx + my * my;
+      const double mn = sqrt(z);
+      const double e = kFo * exp(-(mn - radius) / kSig);
+      fx += e * (z > 0 ? mx / mn : mx);
+      fy += e * (z > 0 ? my / mn : my);
+    }
+    for (int j = 0; j < n_act; ++j) {  // computeSocialForce(index, agents) :237-281
+      const double qx = __shfl(px, base + j, 64), qy = __shfl(py, base + j, 64);
+      const double wx = __shfl(vx, base + j, 64), wy = __shfl(vy, base + j, 64);
+      if (j == g || g >= n_act) continue;
+      const double dfx = qx - px, dfy = qy - py;
+      const double z = dfx * dfx + dfy * dfy;
+      const double nd = sqrt(z);
+      const double ex = z > 0 ? dfx / nd : dfx, ey = z > 0 ? dfy / nd : dfy;
+      const double ivx = kLam * (vx - wx) + ex, ivy = kLam * (vy - wy) + ey;
+      const double il = sqrt(ivx * ivx + ivy * ivy);
+      const double ix = ivx / il, iy = ivy / il;
+      // equal velocities (two standing people): theta is mathematically 0 and the reference gets its libm's last-bit
+      // noise (its thetaSign is then 0 or +-1 by chance); take exactly 0, the convention of the hot path
+      const bool same_vel = (kLam * (vx - wx) == 0.0) && (kLam * (vy - wy) == 0.0);
+      const double theta = same_vel ? 0.0 : proj_wrap(proj_wrap(atan2(ey, ex)) - proj_wrap(atan2(iy, ix)));
+      const double Bq = kGam * il;
+      const double fv = -exp(-nd / Bq - (kNp * Bq * theta) * (kNp * Bq * theta));
+      const double sgn = (theta == 0) ? 0.0 : ((theta > 0) ? 1.0 : -1.0);  // sfm.hpp:265-270
+      const double fa = -sgn * exp(-nd / Bq - (kN * Bq * theta) * (kN * Bq * theta));
+      fx += kFs * (fv * ix + fa * (-iy));
+      fy += kFs * (fv * iy + fa * ix);
+    }
+    // ---- updatePosition (sfm.hpp:525-551)
+    vx += fx * dt; vy += fy * dt;
+    {
+      const double z = vx * vx + vy * vy;
+      const double sp = sqrt(z);
+      if (sp > des) { vx = (z > 0 ? vx / sp : vx) * des; vy = (z > 0 ? vy / sp : vy) * des; }
+    }
+    const double init_yaw = yaw;
+    yaw = proj_wrap(atan2(vy, vx));
+    av = proj_wrap(yaw - init_yaw) / dt;
+    px += vx * dt; py += vy * dt;
+    lv = sqrt(vx * vx + vy * vy);
+    if (has_goal) {
+      const double ddx = gx - px, ddy = gy - py;
+      if (sqrt(ddx * ddx + ddy * ddy) <= grad) has_goal = false;
+    }
+    // ---- refresh each person's obstacle entry (:636-640) and emit people_traj[i+1] (:642-668)
+    if (is_agent) {
+      const int e = proj_obstacle(p, idx, ox, oy, px, py, obx, oby);
+      if (e && !err) err = e;
+    }
+    if (live_scene && g < N) {
+      double* o = out + (size_t)(i + 1) * 6 * N + g;
+      if (is_agent) {
+        o[0] = px; o[N] = py; o[2 * N] = yaw; o[3 * N] = (double)((float)(i + 1) * p.time_step); o[4 * N] = lv; o[5 * N] = av;
+      } else {
+        o[0] = 0.0; o[N] = 0.0; o[2 * N] = 0.0; o[3 * N] = -1.0; o[4 * N] = 0.0; o[5 * N] = 0.0;
+      }
+    }
+  }
+  // per-scene error: any agent lane that hit a grid exception
+  int any = err;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int other = __shfl_xor(any, off, 64);
+    if (off < G && other && !any) any = other;
+  }
+  if (live_scene && g == 0 && p.error) p.error[s] = any;
+}
+
+}  // namespace smpc

@@ -407,3 +407,35 @@ bool Optimizer::optimize(
 }
 
 }  // namespace nav2_social_mpc_controller
+
+// C-callable view of Optimizer::project_people for the test-suite (ctypes): arrays in, arrays out.
+// init_people [N][6], robot_path [T+1][6], od_indexes [h][w] -> out [T+1][N][6]. Returns 0, or -1 if the reference
+// would throw (message in `err`, up to errlen bytes).
+extern "C" int smpc_host_project_people(const double * init_people, int N, const double * robot_path, int T,
+                                        const uint32_t * od_indexes, int od_width, int od_height, float od_resolution,
+                                        double od_origin_x, double od_origin_y, float max_time, float time_step,
+                                        double * out, char * err, int errlen)
+{
+  using namespace nav2_social_mpc_controller;
+  AgentsStates init(N);
+  for (int a = 0; a < N; ++a) for (int f = 0; f < 6; ++f) init[a][f] = init_people[a * 6 + f];
+  AgentTrajectory path(T + 1);
+  for (int k = 0; k <= T; ++k) for (int f = 0; f < 6; ++f) path[k][f] = robot_path[k * 6 + f];
+  obstacle_distance_msgs::msg::ObstacleDistance od;
+  od.info.width = od_width; od.info.height = od_height; od.info.resolution = od_resolution;
+  od.info.origin.position.x = od_origin_x; od.info.origin.position.y = od_origin_y;
+  if (od_indexes) {
+    od.indexes.assign(od_indexes, od_indexes + (size_t)od_width * od_height);
+    od.distances.assign((size_t)od_width * od_height, 0.0f);
+  }
+  try {
+    Optimizer opt;
+    AgentsTrajectories traj = opt.project_people(init, path, od, max_time, time_step);
+    for (size_t k = 0; k < traj.size(); ++k)
+      for (int a = 0; a < N; ++a) for (int f = 0; f < 6; ++f) out[(k * N + a) * 6 + f] = traj[k][a][f];
+  } catch (const std::exception & e) {
+    if (err && errlen > 0) std::snprintf(err, errlen, "%s", e.what());
+    return -1;
+  }
+  return 0;
+}

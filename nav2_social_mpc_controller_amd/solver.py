@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import SmpcEvalOut, SmpcParams, SmpcResultBatch, SmpcSceneBatch
+from ._abi import SmpcEvalOut, SmpcParams, SmpcProjectionBatch, SmpcResultBatch, SmpcSceneBatch
 from .params import OptimizerParams
 from .scenes import SceneBatch
 
@@ -50,6 +50,8 @@ def load_library():
     lib.smpc_solve_batch.restype = C.c_int
     lib.smpc_eval_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.POINTER(SmpcEvalOut)]
     lib.smpc_eval_batch.restype = C.c_int
+    lib.smpc_project_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcProjectionBatch), C.c_void_p, C.c_void_p]
+    lib.smpc_project_people_batch.restype = C.c_int
     lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
     lib.smpc_last_kernel_ms.restype = C.c_double
     if lib.smpc_abi_version() != _abi.SMPC_ABI_VERSION:
@@ -126,6 +128,32 @@ class BatchSolver:
         sb = scenes.to_c()
         _check(self.lib, self.lib.smpc_eval_batch(self._h, C.byref(sb), x.ctypes.data, C.byref(eo)), "smpc_eval_batch")
         return out
+
+    # -- people projection: Optimizer::project_people for B scenes -------------
+    def project_people(self, init_people: np.ndarray, robot_path: np.ndarray, od_indexes: np.ndarray,
+                       od_origin: np.ndarray, od_resolution: float, max_time: float, time_step: float):
+        """init_people [B,N,6], robot_path [B,T+1,6], od_indexes [B or 1,h,w] uint32, od_origin [B or 1,2].
+        Returns (people_proj [B,T+1,6,N], error [B])."""
+        init_people = np.ascontiguousarray(init_people, np.float64)
+        robot_path = np.ascontiguousarray(robot_path, np.float64)
+        od_indexes = np.ascontiguousarray(od_indexes, np.uint32)
+        od_origin = np.ascontiguousarray(od_origin, np.float64)
+        B, N, _ = init_people.shape
+        T = robot_path.shape[1] - 1
+        pb = SmpcProjectionBatch()
+        pb.B, pb.T, pb.N, pb.on_device = B, T, N, 0
+        pb.max_time, pb.time_step = float(max_time), float(time_step)
+        pb.init_people, pb.robot_path = init_people.ctypes.data, robot_path.ctypes.data
+        pb.od_indexes = od_indexes.ctypes.data if od_indexes.size else None
+        pb.od_shared = 1 if od_indexes.shape[0] == 1 else 0
+        pb.od_height, pb.od_width = (int(od_indexes.shape[1]), int(od_indexes.shape[2])) if od_indexes.ndim == 3 else (0, 0)
+        pb.od_resolution = float(od_resolution)
+        pb.od_origin = od_origin.ctypes.data
+        out = np.zeros((B, T + 1, 6, N))
+        err = np.zeros(B, np.int32)
+        _check(self.lib, self.lib.smpc_project_people_batch(self._h, C.byref(pb), out.ctypes.data, err.ctypes.data),
+               "smpc_project_people_batch")
+        return out, err
 
     # -- device-resident path (inputs already in HBM; asynchronous on the handle's stream) -------
     def alloc_results(self, B: int, T: int, device="cuda:0"):

@@ -1,0 +1,160 @@
+"""People projection: Optimizer::project_people + SFM. Three statements of it are compared:
+oracle/pyref_sfm.py (numpy, the checker), the C++ host adapter (CPU) and the HIP kernel behind
+smpc_project_people_batch (GPU)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "nav2_social_mpc_controller_amd", "host")
+
+
+def make_case(seed, N=3, n_valid=2, T=28, grid=120):
+    rng = np.random.default_rng(seed)
+    init = np.zeros((N, 6))
+    init[:, 3] = -1.0
+    for a in range(n_valid):
+        r, phi, hd = rng.uniform(0.8, 3.0), rng.uniform(-np.pi, np.pi), rng.uniform(-np.pi, np.pi)
+        lv = 0.0 if rng.uniform() < 0.2 else rng.uniform(0.2, 1.2)
+        init[a] = [r * np.cos(phi), r * np.sin(phi), hd, 0.0, lv, 0.0]
+    dt = float(np.float32(0.05))
+    path = np.zeros((T + 1, 6))
+    x = y = 0.0
+    th, w = rng.uniform(-np.pi, np.pi), rng.uniform(-0.6, 0.6)
+    for k in range(T + 1):
+        path[k] = [x, y, th, k * dt, 0.6 if k else rng.uniform(0, 0.6), w]
+        x, y, th = x + 0.6 * np.cos(th) * dt, y + 0.6 * np.sin(th) * dt, th + w * dt
+    # nearest-obstacle grid: a handful of obstacle cells, every cell points at the closest one
+    res, origin = np.float32(0.1), np.array([-6.0, -6.0])
+    obs = rng.integers(0, grid, size=(5, 2))
+    yy, xx = np.mgrid[0:grid, 0:grid]
+    d = (xx[None] - obs[:, 0, None, None]) ** 2 + (yy[None] - obs[:, 1, None, None]) ** 2
+    near = obs[np.argmin(d, axis=0)]
+    idx = (near[..., 0] + near[..., 1] * grid).astype(np.uint32)
+    return dict(init=init, path=path, idx=idx, origin=origin, res=float(res), max_time=1.5, dt=0.05, T=T, N=N, grid=grid)
+
+
+def pyref_project(c, convention=False):
+    from oracle import pyref_sfm
+    od = dict(width=c["grid"], height=c["grid"], resolution=c["res"], origin_x=c["origin"][0], origin_y=c["origin"][1], indexes=c["idx"])
+    return pyref_sfm.project_people(c["init"], c["path"], od, c["max_time"], c["dt"], theta_zero_convention=convention)  # [T+1][N][6]
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    lib = C.CDLL(os.path.join(HOST, "libsmpc_host.so"))
+    lib.smpc_host_project_people.restype = C.c_int
+    lib.smpc_host_project_people.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                             C.c_double, C.c_double, C.c_float, C.c_float, C.c_void_p, C.c_char_p, C.c_int]
+    return lib
+
+
+def host_project(lib, c):
+    out = np.zeros((c["T"] + 1, c["N"], 6))
+    err = C.create_string_buffer(256)
+    idx = np.ascontiguousarray(c["idx"], np.uint32)
+    rc = lib.smpc_host_project_people(np.ascontiguousarray(c["init"]).ctypes.data, c["N"], np.ascontiguousarray(c["path"]).ctypes.data,
+                                      c["T"], idx.ctypes.data, c["grid"], c["grid"], c["res"], c["origin"][0], c["origin"][1],
+                                      c["max_time"], c["dt"], out.ctypes.data, err, 256)
+    return rc, out, err.value.decode()
+
+
+@pytest.mark.parametrize("seed,n_valid", [(1, 2), (2, 3), (3, 1), (4, 0)])
+def test_host_cpp_matches_numpy_restatement(hostlib, seed, n_valid):
+    c = make_case(seed, n_valid=n_valid)
+    want = pyref_project(c)
+    rc, got, _ = host_project(hostlib, c)
+    assert rc == 0
+    assert np.max(np.abs(got - want)) < 1e-11
+    assert np.all(want[1:, n_valid:, 3] == -1.0)                      # padded phantoms after the valid agents
+
+
+def test_host_cpp_quirks(hostlib):
+    c = make_case(5)
+    c100 = dict(c, grid=100, idx=np.zeros((100, 100), np.uint32))     # 100 x 100 grid: every person is dropped
+    rc, got, _ = host_project(hostlib, c100)
+    assert rc == 0 and np.all(got[1:, :, 3] == -1.0) and np.array_equal(got[0], c["init"])
+    far = dict(c, init=c["init"].copy())
+    far["init"][0, 0] = 1e3                                           # off the distance grid: the reference throws
+    rc, _, msg = host_project(hostlib, far)
+    assert rc == -1 and "out of bounds" in msg
+
+
+@pytest.mark.gpu
+def test_hip_projection_matches_restatements(hostlib):
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    s = BatchSolver(OptimizerParams.readme())
+    for N, n_valid in ((3, 2), (3, 3), (3, 0), (8, 6), (16, 16)):
+        cases = [make_case(100 + 7 * N + i, N=N, n_valid=n_valid) for i in range(6)]
+        init = np.stack([c["init"] for c in cases])
+        path = np.stack([c["path"] for c in cases])
+        idx = np.stack([c["idx"] for c in cases])
+        origin = np.stack([c["origin"] for c in cases])
+        got, err = s.project_people(init, path, idx, origin, cases[0]["res"], cases[0]["max_time"], cases[0]["dt"])
+        assert np.all(err == 0)
+        for b, c in enumerate(cases):
+            # checker under the theta := 0 convention for exactly equal velocities (two standing people at step 0)
+            want = pyref_project(c, convention=True)                  # [T+1][N][6]
+            assert np.max(np.abs(got[b].transpose(0, 2, 1) - want)) < 1e-9, (N, n_valid, b)
+            literal = pyref_project(c)
+            if N == 3 and np.max(np.abs(literal - want)) == 0.0:      # no libm-noise decision in this case
+                rc, hostres, _ = host_project(hostlib, c)
+                assert rc == 0 and np.max(np.abs(got[b].transpose(0, 2, 1) - hostres)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_projection_error_flags_and_grid_quirk():
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver, SmpcError
+    s = BatchSolver(OptimizerParams.readme())
+    c = make_case(9)
+    bad = c["init"].copy()
+    bad[0, 0] = 1e3
+    init = np.stack([c["init"], bad])
+    path = np.stack([c["path"], c["path"]])
+    got, err = s.project_people(init, path, c["idx"][None], c["origin"][None], c["res"], c["max_time"], c["dt"])
+    assert err.tolist() == [0, 1]                                     # scene 1: cell out of bounds (reference throws)
+    idx100 = np.zeros((1, 100, 100), np.uint32)
+    got, err = s.project_people(init[:1], path[:1], idx100, c["origin"][None], c["res"], c["max_time"], c["dt"])
+    assert np.all(got[0, 1:, 3, :] == -1.0)                           # "NOT valid" grid: every person dropped
+    with pytest.raises(SmpcError):
+        s.project_people(init[:1], path[:1], np.zeros((1, 0, 0), np.uint32), c["origin"][None], c["res"], c["max_time"], c["dt"])
+
+
+@pytest.mark.gpu
+def test_projection_feeds_the_solver(oracle):
+    """f1 -> hot path on the GPU: project the people with the HIP kernel, solve with the HIP kernel, check against
+    the numpy projection + CPU oracle."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.scenes import make_scenes
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 8, 3, n_valid=3, map_cells=80, seed=77, standing_fraction=0.0)
+    s = BatchSolver(prm)
+    T = sc.T
+    grid = 200
+    idx = np.full((1, grid, grid), 5 + 7 * grid, np.uint32)
+    origin = np.array([[-15.0, -15.0]])
+    init = np.ascontiguousarray(sc.people[:, 0].transpose(0, 2, 1))                # [B][N][6]
+    th = np.arctan2(np.diff(sc.path_pts[:, :, 1], axis=1), np.diff(sc.path_pts[:, :, 0], axis=1))
+    th = np.concatenate([th, th[:, -1:]], axis=1)
+    rpath = np.zeros((sc.B, T + 1, 6))
+    rpath[:, :, 0:2], rpath[:, :, 2], rpath[:, :, 4] = sc.path_pts, th, 0.6
+    proj, err = s.project_people(init, rpath, idx, origin, 0.15, 1.5, 0.05)
+    assert np.all(err == 0)
+    sc.people = np.ascontiguousarray(proj)
+    from oracle import pyref_sfm
+    od = dict(width=grid, height=grid, resolution=0.15, origin_x=-15.0, origin_y=-15.0, indexes=idx[0])
+    for b in range(sc.B):
+        want = pyref_sfm.project_people(init[b], rpath[b], od, 1.5, 0.05, theta_zero_convention=True)
+        assert np.max(np.abs(proj[b].transpose(0, 2, 1) - want)) < 1e-9
+    ref = oracle.solve(prm, sc, theta_zero_convention=True)
+    got = s.solve(sc)
+    firm = ref["marginal_decisions"] == 0
+    assert firm.any()
+    assert np.max(np.abs(got["cmds"][firm] - ref["cmds"][firm])) <= 1e-5
