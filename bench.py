@@ -205,6 +205,19 @@ def main():
                          "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
                          "k1_sweep_kernel": {"launch_ms": k1_ms, "achieved": k1_achieved, "frac": k1_achieved / HBM_PEAK_GBS}},
         }
+        if world == 1:
+            # extras of SURVEY §8(d): (ii) end-to-end including PCIe staging, (iii) fixed-40-iteration mode
+            t1 = time.perf_counter()
+            solver.solve(scenes)                      # host pointers: H2D of every input, solve, D2H of every output
+            line["config"]["pcie_inclusive_solves_per_s"] = B / (time.perf_counter() - t1)
+            fixed = BatchSolver(prm.replace(fixed_iterations=1), device=local_rank)
+            frb, fout = fixed.alloc_results(B, T, device)
+            fixed.solve_device(sb, frb)
+            fixed.solve_device(sb, frb)
+            torch.cuda.synchronize(device)
+            fms = fixed.last_kernel_ms()
+            line["config"]["fixed_40_iterations"] = {"launch_ms": fms, "solves_per_s": B / (fms * 1e-3),
+                                                     "mean_sweeps_per_solve": float(fout["evaluations"].float().mean().item())}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py as O
             cores = usable_cores()

@@ -4,7 +4,7 @@ generator SURVEY.md §8(d) specifies (counter-based SplitMix64 keyed by (seed, s
 shard / the CPU oracle regenerate identical scenes with no communication).
 """
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
@@ -49,7 +49,6 @@ class SceneBatch:
     costmap_origin: np.ndarray  # [B or 1,2]
     resolution: float
     costmap_shared: bool = False
-    _keep: list = field(default_factory=list, repr=False)
 
     @property
     def B(self) -> int:

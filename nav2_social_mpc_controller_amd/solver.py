@@ -65,9 +65,6 @@ def _check(lib, rc, what):
         raise SmpcError(f"{what} failed ({rc}): {lib.smpc_last_error().decode()}")
 
 
-RESULT_FIELDS = ("params", "cmds", "path", "status", "reason", "iterations", "evaluations", "initial_cost", "final_cost")
-
-
 class BatchSolver:
     """One solver bound to one HIP device; mirrors Optimizer::initialize + Optimizer::optimize for B scenes."""
 
