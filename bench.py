@@ -74,8 +74,8 @@ def algorithmic_bytes_per_sweep(N, T, P, M):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8192, help="scenes per GPU")
     ap.add_argument("--people", type=int, default=8)
     ap.add_argument("--fixed-iterations", type=int, default=0, help="1: run exactly 40 LM iterations per scene")
@@ -94,7 +94,8 @@ def main():
     from nav2_social_mpc_controller_amd.solver import BatchSolver
 
     rank, local_rank, world = D.env_rank_world()
-    if args.gpus > 1 or world > 1:
+    force_dist = os.environ.get("SMPC_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path with a single rank
+    if args.gpus > 1 or world > 1 or force_dist:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -129,7 +130,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -150,7 +151,7 @@ def main():
     solo_ms = solver.last_kernel_ms()
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
 
@@ -243,7 +244,7 @@ def main():
                               "literal_oracle": {"scenes_without_sign_noise": int(clean.sum()),
                                                  "max_abs_dcmd_on_those": float(dlit[clean].max()) if clean.any() else None}}
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
