@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--people", type=int, default=8)
     ap.add_argument("--fixed-iterations", type=int, default=0, help="1: run exactly 40 LM iterations per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="consecutive steps are issued round-robin on this many HIP streams (one solver handle each)")
     args = ap.parse_args()
 

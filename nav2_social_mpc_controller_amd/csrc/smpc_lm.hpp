@@ -476,11 +476,11 @@ enum Phase { PH_FETCH = 0, PH_INIT = 1, PH_LS = 2, PH_REEVAL = 3, PH_DONE = 4, P
 
 // Slot-uniform LM scalars parked in LDS (offsets into the scal[] block).
 enum Scal { S_COST = 0, S_XNORM, S_GMAX, S_RADIUS, S_DECF, S_MCC, S_GD0, S_DIRMAX, S_PREV_X, S_PREV_V, S_PREV_G,
-            S_CUR_X, S_CUR_V, S_CUR_G, S_INITIAL_COST, S_COUNT };
+            S_CUR_X, S_CUR_V, S_CUR_G, S_INITIAL_COST, S_FIRST_V, S_COUNT };
 
 struct LmRegs {  // slot-uniform integers / flags kept in registers
   int phase, iter, evals, num_invalid, ls_iters, n_samples, status, reason;
-  bool step_successful, at_least_one, prev_vv, prev_gv, cur_vv, cur_gv;
+  bool step_successful, at_least_one, prev_vv, prev_gv, cur_vv, cur_gv, first_vv;
 };
 
 #ifndef SMPC_SOLVE_MIN_WAVES
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   R.phase = PH_FETCH;
   R.iter = R.evals = R.num_invalid = R.ls_iters = R.n_samples = 0;
   R.status = SMPC_NO_CONVERGENCE; R.reason = SMPC_REASON_MAX_ITERATIONS;
-  R.step_successful = R.at_least_one = R.prev_vv = R.prev_gv = R.cur_vv = R.cur_gv = false;
+  R.step_successful = R.at_least_one = R.prev_vv = R.prev_gv = R.cur_vv = R.cur_gv = R.first_vv = false;
   bool ever_loaded = false;
 #ifdef SMPC_STAMPS
   for (int i = 0; i < 8; ++i) c.acc[i] = 0;
@@ -640,6 +640,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
       R.cur_gv = R.cur_vv && isfinite(gd);
       sv[S_CUR_V] = val; sv[S_CUR_G] = gd;
       const double alpha = sv[S_CUR_X];
+      if (R.n_samples == 1) { sv[S_FIRST_V] = val; R.first_vv = R.cur_vv; }  // the full step: candidate if the search fails
       if (R.cur_vv && !(val > sv[S_COST] + 1e-4 * sv[S_GD0] * alpha)) {
         // Armijo satisfied: delta *= alpha; the candidate is this very point
 #pragma unroll
@@ -666,10 +667,21 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
           for (int q = 0; q < P; ++q) xt[q] = clampd(xc[q] + step_size * dl[q], lo(q), hi(q));
           ++R.n_samples;
         } else if (R.n_samples > 1) {
-          // line search failed: delta unchanged, the candidate is the full step again -> re-evaluate it
+          // Line search failed: delta unchanged, the candidate is the full step again (the first sample). Its cost is
+          // known; its Gram is only needed if the step were accepted, which a step that failed the Armijo test at
+          // alpha = 1 cannot be (cost - value_1 < -1e-4 g.delta < 1e-3 model_cost_change). Only in that never-seen case
+          // the point is swept again (PH_REEVAL) so that the accepted state is built from its own Gram.
 #pragma unroll
           for (int q = 0; q < P; ++q) xt[q] = clampd(xc[q] + dl[q], lo(q), hi(q));
-          R.phase = PH_REEVAL;
+          const double v1 = R.first_vv ? sv[S_FIRST_V] : 1.7976931348623157e308;
+          const bool would_accept = R.first_vv && ((sv[S_COST] - v1) / sv[S_MCC] > 1e-3);
+          if (would_accept) {
+            R.phase = PH_REEVAL;
+          } else {
+            R.cur_vv = R.first_vv;
+            sv[S_CUR_V] = v1;
+            candidate();
+          }
         } else {
           candidate();  // the only sample was the full step itself
         }
