@@ -252,3 +252,39 @@ def test_device_resident_path_matches_host_path(Solver):
     assert s.last_kernel_ms() > 0.0
     for k in host:
         assert np.array_equal(rt[k].cpu().numpy(), host[k]), k
+
+
+def _random_params(rng):
+    bl = int(rng.integers(2, 8))
+    ch = int(rng.integers(bl, min(6 * bl, 30) + 1))          # 1..6 parameter blocks
+    return README.replace(
+        control_horizon=ch, parameter_block_length=bl, max_time=float(rng.choice([1.0, 1.5, 2.0])),
+        distance_weight=float(rng.uniform(5, 60)), social_weight=float(rng.uniform(0, 800)),
+        velocity_weight=float(rng.uniform(1, 15)), angle_weight=float(rng.uniform(0, 300)),
+        agent_angle_weight=float(rng.choice([0.0, rng.uniform(1, 60)])), proxemics_weight=float(rng.uniform(0, 120)),
+        velocity_feasibility_weight=float(rng.uniform(0, 10)), goal_align_weight=float(rng.uniform(0, 15)),
+        obstacle_weight=float(rng.uniform(0, 0.3)), max_iterations=int(rng.choice([5, 20, 40])),
+        linear_solver_type=str(rng.choice(["DENSE_SCHUR", "DENSE_QR", "SPARSE_NORMAL_CHOLESKY"])),
+        fn_tol=float(rng.choice([1e-5, 1e-7])))
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_randomised_parameter_sets(Solver, oracle, case):
+    """Random weights / horizons / block lengths / solver types / iteration caps (1..6 parameter blocks, T 18..38)."""
+    rng = np.random.default_rng(7000 + case)
+    prm = _random_params(rng)
+    N = int(rng.integers(1, 12))
+    sc = make_scenes(prm, 48, N, seed=8000 + case, map_cells=int(rng.choice([60, 120, 200])),
+                     n_valid=int(rng.integers(1, N + 1)))
+    CH, bl, nb, P, M, _ = prm.dims(sc.T)
+    assert 1 <= nb <= 6
+    s = Solver(prm)
+    ev_o, ev_g = oracle.evaluate(prm, sc, sc.init_params), s.evaluate(sc, sc.init_params)
+    assert np.max(np.abs(ev_o["jacobian"] - ev_g["jacobian"]) / np.maximum(1.0, np.abs(ev_o["jacobian"]))) < JAC_RTOL
+    rz = oracle.solve(prm, sc, nthreads=16, theta_zero_convention=True)
+    rg = s.solve(sc)
+    firm = rz["marginal_decisions"] == 0
+    assert firm.mean() >= 0.8
+    assert np.max(cmd_err(rg["cmds"][firm], rz["cmds"][firm])) <= CMD_TOL
+    assert np.array_equal(rg["iterations"][firm], rz["iterations"][firm])
+    assert np.array_equal(rg["status"][firm], rz["status"][firm])
