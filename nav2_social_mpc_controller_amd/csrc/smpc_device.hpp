@@ -542,6 +542,20 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       const int end = (b == NB - 1) ? T : (b + 1) * bl;
       const double vdt = xp[2 * b] * dt;
       double aC = 0.0, aS = 0.0, aJC = 0.0, aJS = 0.0;
+      for (; j + 4 <= end; j += 4) {  // 8 LDS reads in flight per trip
+        double cj[4], sj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cj[u] = cs_[j + u]; sj[u] = sn_[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool on = (j + u) <= sl;
+          const double kk = (double)(j + u - start);
+          aC += on ? cj[u] : 0.0;
+          aS += on ? sj[u] : 0.0;
+          aJC = on ? fma(kk, cj[u], aJC) : aJC;
+          aJS = on ? fma(kk, sj[u], aJS) : aJS;
+        }
+      }
       for (; j < end; ++j) {
         const double cj = cs_[j], sj = sn_[j];
         const bool on = j <= sl;
