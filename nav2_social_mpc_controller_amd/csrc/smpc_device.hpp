@@ -63,7 +63,8 @@ struct KParams {
 
 // LDS carve-up (in doubles) of ONE slot.
 struct LdsLayout {
-  int ag;       // (unused: the staged people block lives in the global workspace)
+  int ag;       // [4][N][T]  staged people block (px, py, vx, vy) — stand-alone K1 only; the solve kernel keeps it
+                //            in a global workspace instead (LDS footprint of a persistent wave stays near 10 KB)
   int valid;    // [T]        bit a set = agent a valid at step t (64-bit words)
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
   int inc;      // [2][T]     per-step position increments of the current sweep
@@ -77,11 +78,12 @@ struct LdsLayout {
 
 // with_lm = true is the solve kernel: LM state in LDS, staged people block (px, py, vx, vy per agent and step,
 // re-read every sweep) in an L2-resident global workspace, which keeps the LDS footprint of a wave near 10 KB.
-// false is the stand-alone K1 kernel: a single sweep, which reads the people array directly (no staging at all).
+// false is the stand-alone K1 kernel: a single sweep, people block staged in LDS (every people row is read from HBM
+// once, neighbouring lanes on neighbouring agents).
 __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, bool with_lm) {
   LdsLayout L;
   int o = 0;
-  L.ag = o;
+  L.ag = o; if (!with_lm) o += 4 * T * (N > 0 ? N : 1);
   L.valid = o; o += T;
   L.cs = o; o += 2 * (T + 1);
   L.inc = o; o += 2 * T;
@@ -320,11 +322,10 @@ struct GramView {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// Load the slot's scene constants and stage its people block into LDS (px, py, wx, wy per (agent, step); valid
-// mask per step), compute the agent-angle tags. Executed by all W lanes of the slot (other slots may be masked off).
-// kStaged: also write the staged people block [4][N][T] (px, py, vx, vy) to c.ag (solve kernel); the stand-alone K1
-// kernel reads `people` directly in its only sweep.
-template <int W, bool kStaged>
+// Load the slot's scene constants, stage its people block (px, py, vx, vy per (agent, step)) into c.ag and the valid
+// mask per step into LDS, compute the agent-angle tags. Executed by all W lanes of the slot (other slots may be
+// masked off).
+template <int W>
 __device__ inline void load_scene(Ctx& c, int scene) {
   const KParams& k = *c.kp;
   const int T = k.T, N = k.N, sl = c.sl;
@@ -349,19 +350,19 @@ __device__ inline void load_scene(Ctx& c, int scene) {
     unsigned long long* vmask = reinterpret_cast<unsigned long long*>(c.lds + c.L.valid);
     const double* ppl = k.people + s * (size_t)(T + 1) * 6 * N;
     const int TN = T * N;
-    // element q = a*T + t of each component plane; people_proj[t+1] field f agent a is at ((t+1)*6 + f)*N + a
-    if (kStaged) {
-      for (int q = sl; q < TN; q += W) {
-        const int a = q / T, t = q - a * T;
-        const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
-        const double px = f[0], py = f[N], yaw = f[2 * N], lv = f[4 * N];
-        double sn, cs;
-        sincos(yaw, &sn, &cs);
-        ag[q] = px;
-        ag[TN + q] = py;
-        ag[2 * TN + q] = lv * cs;  // aVel, social_work:187-188
-        ag[3 * TN + q] = lv * sn;
-      }
+    // people_proj[t+1] field f agent a is at ((t+1)*6 + f)*N + a. Gather with the agent index fastest across lanes
+    // (neighbouring lanes read neighbouring doubles of one people row); element (a, t) lands at a*T + t of each plane.
+    for (int e = sl; e < TN; e += W) {
+      const int t = e / N, a = e - t * N;
+      const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
+      const double px = f[0], py = f[N], yaw = f[2 * N], lv = f[4 * N];
+      double sn, cs;
+      sincos(yaw, &sn, &cs);
+      const int q = a * T + t;
+      ag[q] = px;
+      ag[TN + q] = py;
+      ag[2 * TN + q] = lv * cs;  // aVel, social_work:187-188
+      ag[3 * TN + q] = lv * sn;
     }
     if (sl < T) {
       const double* f = ppl + (size_t)(sl + 1) * 6 * N;
@@ -405,7 +406,7 @@ __device__ inline void load_scene(Ctx& c, int scene) {
 // reduced over the slot in every lane of the slot.
 // When out_r / out_J are non-null (stand-alone K1) the rows are also written to HBM in the reference order.
 // ------------------------------------------------------------------------------------------------
-template <int NB, int W, bool kStaged>
+template <int NB, int W>
 __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J) {
   constexpr int P = 2 * NB;
   const KParams& k = *c.kp;
@@ -475,25 +476,13 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const int TN = T * N;
     const unsigned long long vm = vmask[tl];
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
-    // software prefetch of the next agent's entry: staged block (L2-resident workspace) in the solve kernel, the raw
-    // people array (x, y, yaw, lv of people_proj[sl+1]) in the stand-alone K1 kernel
-    const double* raw = k.people + (size_t)c.scene * (T + 1) * 6 * N + (size_t)(tl + 1) * 6 * N;
-    double npx, npy, nwx, nwy;
-    if (kStaged) { npx = ag[tl]; npy = ag[TN + tl]; nwx = ag[2 * TN + tl]; nwy = ag[3 * TN + tl]; }
-    else { npx = raw[0]; npy = raw[N]; nwx = raw[2 * N]; nwy = raw[4 * N]; }
+    // software prefetch of the next agent's entry of the staged block (L2-resident workspace in the solve kernel,
+    // LDS in the stand-alone K1 kernel)
+    double npx = ag[tl], npy = ag[TN + tl], nwx = ag[2 * TN + tl], nwy = ag[3 * TN + tl];
 #pragma unroll 2  // two agents per trip: measured +4% on the fused solve kernel (more independent work per wave)
     for (int a = 0; a < N; ++a) {
       double apx = npx, apy = npy, awx = nwx, awy = nwy;
-      if (a + 1 < N) {
-        if (kStaged) { const int q = (a + 1) * T + tl; npx = ag[q]; npy = ag[TN + q]; nwx = ag[2 * TN + q]; nwy = ag[3 * TN + q]; }
-        else { npx = raw[a + 1]; npy = raw[N + a + 1]; nwx = raw[2 * N + a + 1]; nwy = raw[4 * N + a + 1]; }
-      }
-      if (!kStaged) {  // (yaw, lv) -> aVel, social_work:187-188
-        double sn, cs;
-        sincos(awx, &sn, &cs);
-        const double lv = awy;
-        awx = lv * cs; awy = lv * sn;
-      }
+      if (a + 1 < N) { const int q = (a + 1) * T + tl; npx = ag[q]; npy = ag[TN + q]; nwx = ag[2 * TN + q]; nwy = ag[3 * TN + q]; }
       const bool valid = (vm >> a) & 1ull;
       const double dx = X - apx, dy = Y - apy;
       const double d2 = dx * dx + dy * dy;

@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
       if (c.sl == 0) scene = atomicAdd(k.queue, 1);
       scene = __shfl(scene, slot * W, 64);
       if (scene < k.B) {
-        load_scene<W, true>(c, scene);
+        load_scene<W>(c, scene);
         ever_loaded = true;
         const double* xin = k.init_params + (size_t)scene * P;
         double xn = 0.0;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         R.step_successful = true; R.at_least_one = false;
       } else {
         if (!ever_loaded) {  // keep the sweep's memory accesses in bounds for a slot that never got a scene
-          load_scene<W, true>(c, 0);
+          load_scene<W>(c, 0);
           ever_loaded = true;
 #pragma unroll
           for (int q = 0; q < P; ++q) xt[q] = 0.0;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     SMPC_STAMP(c, 0);  // fetch + load_scene
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
-    const GramView GH = sweep<NB, W, true>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    const GramView GH = sweep<NB, W>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
     const bool finite = gram_finite<P>(GH);
     const double val = 0.5 * GH(P, P);
     bool new_iteration = false;
@@ -812,8 +812,11 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 }
 
 // K1 stand-alone: one sweep per scene at given parameters, rows written to HBM (parity checks, roofline runs).
+#ifndef SMPC_EVAL_MIN_WAVES
+#define SMPC_EVAL_MIN_WAVES 1
+#endif
 template <int NB, int W>
-__global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
+__global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(const KParams k) {
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
   extern __shared__ double lds_all[];
@@ -826,11 +829,11 @@ __global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
   c.lds = lds_all + (size_t)slot * c.L.total;
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
-  c.ag = nullptr;  // K1 reads the people array directly
+  c.ag = c.lds + c.L.ag;  // staged people block in LDS
   const int scene_raw = blockIdx.x * S + slot;
   const bool live = scene_raw < k.B;
   const int scene = live ? scene_raw : k.B - 1;
-  load_scene<W, false>(c, scene);
+  load_scene<W>(c, scene);
   const size_t s = scene;
   double* out_r = (live && k.e_residuals) ? k.e_residuals + s * k.e_M : nullptr;
   double* out_J = (live && k.e_jacobian) ? k.e_jacobian + s * (size_t)k.e_M * P : nullptr;
@@ -841,7 +844,7 @@ __global__ __launch_bounds__(64) void smpc_eval_kernel(const KParams k) {
       if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)i * P + q] = 0.0;
     }
   }
-  const GramView G = sweep<NB, W, false>(c, k.e_x + s * P, out_r, out_J);
+  const GramView G = sweep<NB, W>(c, k.e_x + s * P, out_r, out_J);
   if (live && c.sl == 0 && k.e_cost) k.e_cost[s] = 0.5 * G(P, P);
   if (live && k.e_gradient && c.sl < P) k.e_gradient[s * P + c.sl] = G(c.sl, P);
 }
