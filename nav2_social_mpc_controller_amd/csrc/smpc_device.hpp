@@ -352,17 +352,31 @@ __device__ inline void load_scene(Ctx& c, int scene) {
     const int TN = T * N;
     // people_proj[t+1] field f agent a is at ((t+1)*6 + f)*N + a. Gather with the agent index fastest across lanes
     // (neighbouring lanes read neighbouring doubles of one people row); element (a, t) lands at a*T + t of each plane.
-    for (int e = sl; e < TN; e += W) {
-      const int t = e / N, a = e - t * N;
-      const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
-      const double px = f[0], py = f[N], yaw = f[2 * N], lv = f[4 * N];
-      double sn, cs;
-      sincos(yaw, &sn, &cs);
-      const int q = a * T + t;
-      ag[q] = px;
-      ag[TN + q] = py;
-      ag[2 * TN + q] = lv * cs;  // aVel, social_work:187-188
-      ag[3 * TN + q] = lv * sn;
+    // Four elements per trip, all 16 loads issued before the first use (the stand-alone K1 kernel is bound by this
+    // chain of HBM latencies otherwise).
+    for (int e0 = sl; e0 < TN; e0 += 4 * W) {
+      double gx[4], gy[4], gyaw[4], glv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = min(e0 + u * W, TN - 1);
+        const int t = e / N, a = e - t * N;
+        const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
+        gx[u] = f[0]; gy[u] = f[N]; gyaw[u] = f[2 * N]; glv[u] = f[4 * N];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * W;
+        if (e < TN) {
+          const int t = e / N, a = e - t * N;
+          double sn, cs;
+          sincos(gyaw[u], &sn, &cs);
+          const int q = a * T + t;
+          ag[q] = gx[u];
+          ag[TN + q] = gy[u];
+          ag[2 * TN + q] = glv[u] * cs;  // aVel, social_work:187-188
+          ag[3 * TN + q] = glv[u] * sn;
+        }
+      }
     }
     if (sl < T) {
       const double* f = ppl + (size_t)(sl + 1) * 6 * N;
@@ -370,20 +384,31 @@ __device__ inline void load_scene(Ctx& c, int scene) {
       // a7 AgentAngle tag: depends on constants only (critics/agent_angle_cost_function.hpp:130-190)
       int closest = -1;
       double best = INFINITY;
-      for (int a = 0; a < N; ++a) {
-        if (f[3 * N + a] != -1.0) m |= (1ull << a);  // social_work:175
-        const double ddx = f[a] - x0, ddy = f[N + a] - y0;
-        const double d2 = ddx * ddx + ddy * ddy;
-        if (d2 < best && f[4 * N + a] > 0.05) { best = d2; closest = a; }
+      for (int a0 = 0; a0 < N; a0 += 4) {  // loads of four agents in flight at a time
+        double ft[4], fx[4], fy[4], fl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int a = min(a0 + u, N - 1);
+          ft[u] = f[3 * N + a]; fx[u] = f[a]; fy[u] = f[N + a]; fl[u] = f[4 * N + a];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int a = a0 + u;
+          if (a < N) {
+            if (ft[u] != -1.0) m |= (1ull << a);  // social_work:175
+            const double ddx = fx[u] - x0, ddy = fy[u] - y0;
+            const double d2 = ddx * ddx + ddy * ddy;
+            if (d2 < best && fl[u] > 0.05) { best = d2; closest = a; }
+          }
+        }
       }
       vmask[sl] = m;
       if (closest >= 0 && !(best > 4.0)) {
         const double ax = f[closest], ay = f[N + closest], ayaw = f[2 * N + closest];
         const double agent_angle_initial = atan2(ay - y0, ax - x0);
-        const double hd = ayaw - yaw0;
-        const double heading_diff = atan2(sin(hd), cos(hd));
-        const double rel0 = agent_angle_initial - yaw0;
-        const double rel = atan2(sin(rel0), cos(rel0));
+        // atan2(sin u, cos u) of the reference (:148-152) restated as the range reduction wrap_angle(u)
+        const double heading_diff = wrap_angle(ayaw - yaw0);
+        const double rel = wrap_angle(agent_angle_initial - yaw0);
         const double kThr = M_PI / 6.0, kUp = 5 * M_PI / 6.0;
         if (heading_diff <= -kUp || heading_diff >= kThr) {
           if (!(rel < 0.0)) aa_target = yaw0 + (-(M_PI / 6.0));

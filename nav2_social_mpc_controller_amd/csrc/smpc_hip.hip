@@ -168,21 +168,21 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
       h->ws_ag_bytes = need;
     }
     k.ws_ag = h->ws_ag;
-#ifdef SMPC_STAMPS
-    {  // diagnostic build: per-wave phase cycle sums, dumped to stderr after the launch
-      static unsigned long long* d_stamps = nullptr; static int cap = 0;
-      if (grid > cap) { if (d_stamps) (void)hipFree(d_stamps); SMPC_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_stamps), (size_t)grid * 12 * sizeof(unsigned long long))); cap = grid; }
-      k.stamps = d_stamps;
-    }
-#endif
   }
+#ifdef SMPC_STAMPS
+  {  // diagnostic build: per-wave phase cycle sums, dumped to stderr after the launch
+    static unsigned long long* d_stamps = nullptr; static int cap = 0;
+    if (grid > cap) { if (d_stamps) (void)hipFree(d_stamps); SMPC_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&d_stamps), (size_t)grid * 12 * sizeof(unsigned long long))); cap = grid; }
+    k.stamps = d_stamps;
+  }
+#endif
   SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(fn, dim3(grid), dim3(smpc::kWave), shmem, h->stream, k);
   SMPC_HIP_CHECK(hipGetLastError());
   SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
 #ifdef SMPC_STAMPS
-  if (!eval) {
+  {
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
     std::vector<unsigned long long> hs((size_t)grid * 12);
     SMPC_HIP_CHECK(hipMemcpy(hs.data(), k.stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -190,7 +190,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     for (int g = 0; g < grid; ++g) for (int i = 0; i < 12; ++i) tot[i] += (double)hs[(size_t)g * 12 + i];
     double all = 0; for (int i = 0; i < 8; ++i) all += tot[i];
     static const char* names[8] = {"fetch+load_scene", "theta+sincos", "xy-loop", "agent-loop", "sens-loop", "rows+mfma+gram", "lm+output", "ls-interpolation"};
-    std::fprintf(stderr, "[stamps] grid=%d mean cycles/wave=%.0f:", grid, all / grid);
+    std::fprintf(stderr, "[stamps %s] grid=%d mean cycles/wave=%.0f:", eval ? "K1" : "solve", grid, all / grid);
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * tot[i] / all);
     std::fprintf(stderr, " | rows split: people-critics=%.1f%% vel/goal/dist=%.1f%% obstacle=%.1f%% (rest of rows = feas + gram out)\n",
                  100.0 * tot[8] / all, 100.0 * tot[9] / all, 100.0 * tot[10] / all);

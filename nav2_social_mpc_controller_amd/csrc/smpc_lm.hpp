@@ -268,9 +268,6 @@ template <int nc> __device__ inline double eval_poly_reg(const double (&p)[nc], 
   return v;
 }
 
-// Real parts of the 4 roots of a quartic q[0] x^4 + ... + q[4] (q[0] != 0): Aberth-Ehrlich with the four roots
-// iterated simultaneously on 4 neighbouring lanes (lane & 3 = root index), same start points and stopping rule
-// as poly_roots_real(). Returns all four real parts in every lane.
 // 1/x to ~1e-16 relative: hardware estimate + two Newton steps (only used where a last-bit error is harmless).
 __device__ inline double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
@@ -279,60 +276,70 @@ __device__ inline double fast_rcp(double x) {
   return r;
 }
 
-__device__ inline void quartic_roots_real_lanes(const double (&q)[5], double (&roots)[4]) {
+// Horner value and derivative of a degree-D polynomial p[0] x^D + ... + p[D].
+template <int D> __device__ inline void horner_d(const double (&p)[D + 1], double x, double& f, double& df) {
+  double v = p[0], d = 0.0;
+#pragma unroll
+  for (int i = 1; i <= D; ++i) { d = fma(d, x, v); v = fma(v, x, p[i]); }
+  f = v; df = d;
+}
+
+// The root of p inside [a, b], a <= b, given that p is monotone there: Newton from the midpoint, kept inside the
+// shrinking sign-change bracket (bisection whenever a Newton step leaves it). NaN if p does not change sign on [a, b].
+template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1], double a, double b) {
+  double fa, fb, t;
+  horner_d<D>(p, a, fa, t);
+  horner_d<D>(p, b, fb, t);
+  if (fa == 0.0) return a;
+  if (fb == 0.0) return b;
+  if (!((fa < 0.0) != (fb < 0.0)) || !(fa == fa) || !(fb == fb)) return __builtin_nan("");
+  const bool neg_lo = fa < 0.0;
+  double xl = a, xh = b, x = 0.5 * (a + b);
+  for (int it = 0; it < 80; ++it) {
+    double fx, dfx;
+    horner_d<D>(p, x, fx, dfx);
+    if (fx == 0.0) break;
+    if ((fx < 0.0) == neg_lo) xl = x; else xh = x;
+    double xn = x - fx * fast_rcp(dfx);
+    if (!(xn > xl && xn < xh)) xn = 0.5 * (xl + xh);
+    const bool done = fabs(xn - x) <= 4e-16 * fabs(xn);
+    x = xn;
+    if (done) break;
+  }
+  return x;
+}
+
+// Real roots of the quartic q (q[0] != 0) inside [lo, hi] — the only roots of the derivative that can win the
+// minimisation of the interpolating quintic (the real part of a complex pair, which the reference's companion-matrix /
+// this repository's Aberth fallback also offer as candidates, is never a critical point and so never below the minimum
+// over {lo, hi, real critical points}). Isolation by monotone pieces: the roots of q'' (quadratic, closed form) cut
+// [lo, hi] into <= 3 pieces on which q' is monotone; its <= 3 roots there cut [lo, hi] into <= 4 pieces on which q is
+// monotone. Four neighbouring lanes take one piece each (lane & 3); roots[j] is NaN where piece j holds no root.
+__device__ inline void quartic_roots_in_range_lanes(const double (&q)[5], double lo, double hi, double (&roots)[4]) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 3, base = lane & ~3;
-  double cm[5];
-  const double inv_q0 = 1.0 / q[0];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) cm[i] = q[i] * inv_q0;
-  cm[0] = 1.0;
-  double radius = 0.0;
-  radius = fmax(radius, fabs(cm[1]));
-  radius = fmax(radius, sqrt(fabs(cm[2])));
-  radius = fmax(radius, cbrt(fabs(cm[3])));
-  radius = fmax(radius, sqrt(sqrt(fabs(cm[4]))));
-  radius = fmax(2.0 * radius, 1e-300);
-  double sn, cs;
-  sincos(2.0 * M_PI * r / 4 + 0.4, &sn, &cs);
-  double zr = radius * cs, zi = radius * sn;
-  // The Aberth correction only has to vanish at a root (that is decided by the Horner value of the polynomial), so
-  // the reciprocals inside it use the fast form; the fixed point — the root — is unaffected.
-  for (int it = 0; it < 200; ++it) {
-    double pr = cm[0], pi = 0.0, dr = 0.0, di = 0.0;
-#pragma unroll
-    for (int kk = 1; kk <= 4; ++kk) {
-      const double ndr = dr * zr - di * zi + pr, ndi = dr * zi + di * zr + pi;
-      dr = ndr; di = ndi;
-      const double npr = pr * zr - pi * zi + cm[kk], npi = pr * zi + pi * zr;
-      pr = npr; pi = npi;
-    }
-    double sr = 0.0, si = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const double ojr = __shfl(zr, base + j, 64), oji = __shfl(zi, base + j, 64);
-      const double er = zr - ojr, ei = zi - oji;
-      const double inv_ee = fast_rcp(fmax(er * er + ei * ei, 1e-300));
-      if (j != r) { sr = fma(er, inv_ee, sr); si = fma(-ei, inv_ee, si); }
-    }
-    double rel2 = 0.0;
-    if (!(pr == 0.0 && pi == 0.0)) {
-      const double inv_dd = fast_rcp(dr * dr + di * di);
-      const double rr = (pr * dr + pi * di) * inv_dd, ri = (pi * dr - pr * di) * inv_dd;
-      const double qr = 1.0 - (rr * sr - ri * si), qi = -(rr * si + ri * sr);
-      const double inv_qq = fast_rcp(qr * qr + qi * qi);
-      const double str = (rr * qr + ri * qi) * inv_qq, sti = (ri * qr - rr * qi) * inv_qq;
-      zr -= str; zi -= sti;
-      // |step| < 1e-15 |z|  <=>  |step|^2 < 1e-30 |z|^2
-      const double z2 = fmax(1e-300, zr * zr + zi * zi);
-      rel2 = (str * str + sti * sti) - 1e-30 * z2;  // > 0: not converged
-    }
-    rel2 = fmax(rel2, __shfl_xor(rel2, 1, 64));
-    rel2 = fmax(rel2, __shfl_xor(rel2, 2, 64));
-    if (!(rel2 > 0.0)) break;
+  const double A = 12.0 * q[0], Bq = 6.0 * q[1], C = 2.0 * q[2];
+  double e0 = lo, e1 = lo;
+  const double D = Bq * Bq - 4.0 * A * C;
+  if (D > 0.0) {
+    const double t = -0.5 * (Bq + copysign(sqrt(D), Bq));
+    const double x1 = t / A, x2 = C / t;
+    e0 = fmin(fmax(fmin(x1, x2), lo), hi);
+    e1 = fmin(fmax(fmax(x1, x2), lo), hi);
   }
+  const double d1[4] = {4.0 * q[0], 3.0 * q[1], 2.0 * q[2], q[3]};
+  const double pa = (r == 0) ? lo : (r == 1) ? e0 : e1;
+  const double pb = (r == 0) ? e0 : (r == 1) ? e1 : hi;
+  const double s = bracketed_root<3>(d1, pa, pb);
+  const double s0 = __shfl(s, base + 0, 64), s1 = __shfl(s, base + 1, 64), s2 = __shfl(s, base + 2, 64);
+  const double b1 = (s0 == s0) ? s0 : lo;
+  const double b2 = (s1 == s1) ? fmax(s1, b1) : b1;
+  const double b3 = (s2 == s2) ? fmax(s2, b2) : b2;
+  const double ca = (r == 0) ? lo : (r == 1) ? b1 : (r == 2) ? b2 : b3;
+  const double cb = (r == 0) ? b1 : (r == 1) ? b2 : (r == 2) ? b3 : hi;
+  const double root = bracketed_root<4>(q, ca, cb);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) roots[j] = __shfl(zr, base + j, 64);
+  for (int j = 0; j < 4; ++j) roots[j] = __shfl(root, base + j, 64);
 }
 
 // MinimizeInterpolatingPolynomial for the two common shapes: {lower, current} with all values and gradients valid
@@ -408,7 +415,7 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
   const double vhi = eval_poly_reg<nc>(poly, hi);
   if (vhi < opt_v) { opt_v = vhi; opt_x = hi; }
   double roots[4];
-  quartic_roots_real_lanes(dq, roots);
+  quartic_roots_in_range_lanes(dq, lo, hi, roots);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const double rt = roots[i];
@@ -830,10 +837,16 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
   c.ag = c.lds + c.L.ag;  // staged people block in LDS
+#ifdef SMPC_STAMPS
+  for (int i = 0; i < 8; ++i) c.acc[i] = 0;
+  for (int i = 0; i < 4; ++i) c.acc2[i] = 0;
+  c.t_last = __builtin_amdgcn_s_memtime();
+#endif
   const int scene_raw = blockIdx.x * S + slot;
   const bool live = scene_raw < k.B;
   const int scene = live ? scene_raw : k.B - 1;
   load_scene<W>(c, scene);
+  SMPC_STAMP(c, 0);
   const size_t s = scene;
   double* out_r = (live && k.e_residuals) ? k.e_residuals + s * k.e_M : nullptr;
   double* out_J = (live && k.e_jacobian) ? k.e_jacobian + s * (size_t)k.e_M * P : nullptr;
@@ -847,6 +860,13 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
   const GramView G = sweep<NB, W>(c, k.e_x + s * P, out_r, out_J);
   if (live && c.sl == 0 && k.e_cost) k.e_cost[s] = 0.5 * G(P, P);
   if (live && k.e_gradient && c.sl < P) k.e_gradient[s * P + c.sl] = G(c.sl, P);
+#ifdef SMPC_STAMPS
+  SMPC_STAMP(c, 6);
+  if (k.stamps && lane == 0) {
+    for (int i = 0; i < 8; ++i) k.stamps[(size_t)blockIdx.x * 12 + i] = c.acc[i];
+    for (int i = 0; i < 4; ++i) k.stamps[(size_t)blockIdx.x * 12 + 8 + i] = c.acc2[i];
+  }
+#endif
 }
 
 }  // namespace smpc
