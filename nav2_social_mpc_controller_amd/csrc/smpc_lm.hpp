@@ -301,8 +301,12 @@ template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1
     if (fx == 0.0) break;
     if ((fx < 0.0) == neg_lo) xl = x; else xh = x;
     double xn = x - fx * fast_rcp(dfx);
-    if (!(xn > xl && xn < xh)) xn = 0.5 * (xl + xh);
-    const bool done = fabs(xn - x) <= 4e-16 * fabs(xn);
+    const bool newton = xn > xl && xn < xh;
+    if (!newton) xn = 0.5 * (xl + xh);
+    // A Newton step below 1e-9 |x| leaves an error of the order of its square; waiting for the step itself to reach
+    // round-off would spin on polynomials whose Horner value is noisier than that (measured: 7% of the solve kernel).
+    const double dx = fabs(xn - x);
+    const bool done = (newton && dx <= 1e-9 * fabs(xn)) || dx <= 4e-16 * fabs(xn);
     x = xn;
     if (done) break;
   }
@@ -430,40 +434,42 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
   return true;
 }
 
-// In-register Cholesky solve of (Hs + diag(D2)) y = gs for P <= 20 (fully unrolled, packed lower triangle).
+// In-register Cholesky solve of (H + diag(D2)) y = g for P <= 20 (fully unrolled); H is the packed lower triangle
+// Hl[tri(i, j)], j <= i.
+__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 template <int P>
-__device__ inline bool cholesky_solve(const double* Hs, const double* D2, const double* gs, double (&y)[P]) {
+__device__ inline bool cholesky_solve(const double (&Hl)[P * (P + 1) / 2], const double (&D2)[P], const double (&g)[P],
+                                      double (&y)[P]) {
   double Lm[P * (P + 1) / 2], invd[P];
-  auto li = [](int i, int j) { return i * (i + 1) / 2 + j; };  // j <= i
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < P; ++j) {
-    double d = Hs[j * P + j] + D2[j];
+    double d = Hl[tri(j, j)] + D2[j];
 #pragma unroll
-    for (int kk = 0; kk < j; ++kk) d -= Lm[li(j, kk)] * Lm[li(j, kk)];
+    for (int kk = 0; kk < j; ++kk) d -= Lm[tri(j, kk)] * Lm[tri(j, kk)];
     if (!(d > 0.0) || !isfinite(d)) ok = false;
     const double inv = rsqrt(d);  // 1 / l_jj; l_jj itself is never needed
     invd[j] = inv;
 #pragma unroll
     for (int i = j + 1; i < P; ++i) {
-      double v = Hs[i * P + j];
+      double v = Hl[tri(i, j)];
 #pragma unroll
-      for (int kk = 0; kk < j; ++kk) v -= Lm[li(i, kk)] * Lm[li(j, kk)];
-      Lm[li(i, j)] = v * inv;
+      for (int kk = 0; kk < j; ++kk) v -= Lm[tri(i, kk)] * Lm[tri(j, kk)];
+      Lm[tri(i, j)] = v * inv;
     }
   }
 #pragma unroll
   for (int i = 0; i < P; ++i) {
-    double v = gs[i];
+    double v = g[i];
 #pragma unroll
-    for (int kk = 0; kk < i; ++kk) v -= Lm[li(i, kk)] * y[kk];
+    for (int kk = 0; kk < i; ++kk) v -= Lm[tri(i, kk)] * y[kk];
     y[i] = v * invd[i];
   }
 #pragma unroll
   for (int i = P - 1; i >= 0; --i) {
     double v = y[i];
 #pragma unroll
-    for (int kk = i + 1; kk < P; ++kk) v -= Lm[li(kk, i)] * y[kk];
+    for (int kk = i + 1; kk < P; ++kk) v -= Lm[tri(kk, i)] * y[kk];
     y[i] = v * invd[i];
   }
   return ok;
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   c.ag = k.ws_ag + ((size_t)blockIdx.x * S + slot) * 4 * k.T * (k.N > 0 ? k.N : 1);
   const smpc_params& prm = k.prm;
   const int T = k.T;
-  double* Hs = c.lds + c.L.lm;   // [P*P] scaled J^T J at the current point
+  double* Hs = c.lds + c.L.lm;   // [P*P reserved] scaled J^T J at the current point, packed lower triangle tri(i, j)
   double* gs = Hs + P * P;       // [P] scaled gradient
   double* gu = gs + P;           // [P] unscaled gradient
   double* xc = gu + P;           // [P] current point
@@ -579,16 +585,18 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     // ---------------------------------------------------------------- advance the slot's state machine
     auto adopt_trial_point = [&]() {  // x <- xt, Hs/gs/gu/gmax from G (scaled by the fixed Jacobi scaling)
       double xn = 0.0, gmax = 0.0;
+      double scr[P];
+#pragma unroll
+      for (int a = 0; a < P; ++a) scr[a] = sc[a];
 #pragma unroll
       for (int a = 0; a < P; ++a) {
         const double xa = xt[a];
         xc[a] = xa;
         xn += xa * xa;
-        const double sa = sc[a];
 #pragma unroll
-        for (int b = 0; b < P; ++b) Hs[a * P + b] = GH(a, b) * sa * sc[b];
+        for (int b = 0; b <= a; ++b) Hs[tri(a, b)] = GH(a, b) * scr[a] * scr[b];  // the Gram is bitwise symmetric
         const double g = GH(a, P);
-        gu[a] = g; gs[a] = g * sa;
+        gu[a] = g; gs[a] = g * scr[a];
         gmax = fmax(gmax, fabs(xa - clampd(xa - g, lo(a), hi(a))));
       }
       sv[S_XNORM] = sqrt(xn);
@@ -708,14 +716,18 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         if (sv[S_RADIUS] <= 1e-32) { R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_MIN_RADIUS; R.phase = PH_DONE; break; }
         ++R.iter;
         R.step_successful = false;
-        double step[P], D2[P];
+        double step[P], D2[P], Hl[P * (P + 1) / 2], gsr[P];
         const double radius = sv[S_RADIUS];
+#pragma unroll
+        for (int q = 0; q < P * (P + 1) / 2; ++q) Hl[q] = Hs[q];  // one batch of LDS reads for the whole iteration
+#pragma unroll
+        for (int q = 0; q < P; ++q) gsr[q] = gs[q];
         const double inv_radius = 1.0 / radius;
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-          D2[q] = clampd(Hs[q * P + q], 1e-6, 1e32) * inv_radius;  // (sqrt(diag / radius))^2 of the LM strategy (A.6)
+          D2[q] = clampd(Hl[tri(q, q)], 1e-6, 1e32) * inv_radius;  // (sqrt(diag / radius))^2 of the LM strategy (A.6)
         }
-        bool valid = cholesky_solve<P>(Hs, D2, gs, step);
+        bool valid = cholesky_solve<P>(Hl, D2, gsr, step);
         double mcc = 0.0;
 #pragma unroll
         for (int q = 0; q < P; ++q) { if (!isfinite(step[q])) valid = false; step[q] = -step[q]; }
@@ -723,10 +735,10 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
           double sg = 0.0, sHs = 0.0;
 #pragma unroll
           for (int a = 0; a < P; ++a) {
-            sg += step[a] * gs[a];
+            sg += step[a] * gsr[a];
             double row = 0.0;
 #pragma unroll
-            for (int b = 0; b < P; ++b) row += Hs[a * P + b] * step[b];
+            for (int b = 0; b < P; ++b) row += Hl[a >= b ? tri(a, b) : tri(b, a)] * step[b];
             sHs += step[a] * row;
           }
           mcc = -sg - 0.5 * sHs;
