@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 1
+#define SMPC_ABI_VERSION 2
 #define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20 */
 
 /* linear_solver_type: mirrors OptimizerParams::solver_types (optimizer.hpp:71-77). */
@@ -197,6 +197,48 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* scenes, const double
  * error [B] (enum smpc_projection_error; may be NULL). Returns SMPC_ERR_INVALID_ARG for an empty / malformed grid
  * (the reference throws, src/optimizer.cpp:676-687). */
 int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, double* people_proj, int32_t* error);
+
+/* ---- warm start / input formatting for B scenes ------------------------------------------------
+ * TrajectoryMemory (trajectory_memory.hpp:30-49; a process-wide singleton in the reference) as one caller-owned record
+ * per scene. Yaws are stored as doubles, as tf2::getYaw reads the stored orientation back. */
+typedef struct smpc_memory_batch {
+  double* prev_path;  /* [B][T+1][3] previous_path.poses: x, y, yaw */
+  double* prev_cmds;  /* [B][T+1][2] previous_cmds: linear.x, angular.z */
+  int32_t* valid;     /* [B] 0 while previous_path.poses.size() == 0 (src/optimizer.cpp:177) */
+} smpc_memory_batch;
+
+/* Optimizer::format_to_optimize (src/optimizer.cpp:484-551) for B scenes whose incoming path has already been cut to
+ * T + 1 poses (the cut to round(max_time / time_step) - 1 poses, :492-497, is a host-side length decision), followed by
+ * what Optimizer::optimize derives from its result before building the problem (:197-261). Scenes with an empty memory
+ * record first store the incoming path / cmds in it (:177-183) and then blend with that copy, like the reference. */
+typedef struct smpc_format_batch {
+  int32_t B;
+  int32_t T;          /* path has T + 1 poses */
+  int32_t on_device;  /* 0: host pointers (memory record included), 1: device pointers; outputs follow */
+  float time_step;
+  float current_path_w; /* OptimizerParams::current_path_w / current_cmds_w (optimizer.hpp:93-94, floats) */
+  float current_cmds_w;
+  const double* path;  /* [B][T+1][3] x, y, tf2::getYaw(orientation) of the trajectorizer path */
+  const double* cmds;  /* [B][T+1][2] trajectorizer commands (entries 0..T-1 are read) */
+  const double* speed; /* [B][2] current robot twist linear.x, angular.z */
+  smpc_memory_batch memory;
+} smpc_format_batch;
+
+typedef struct smpc_format_out {
+  double* robot_status; /* [B][T+1][6] optim_status: x, y, yaw, t, lv, av (input of smpc_project_people_batch) */
+  double* pose0;        /* [B][3]      -> smpc_scene_batch.pose0 */
+  double* init_params;  /* [B][P]      -> smpc_scene_batch.init_params (P from smpc_dims) */
+  double* path_pts;     /* [B][T+1][2] -> smpc_scene_batch.path_pts */
+  double* goal_yaw;     /* [B]         -> smpc_scene_batch.goal_yaw */
+} smpc_format_out;
+
+int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, smpc_format_out* out);
+
+/* The TrajectoryMemory store at the end of Optimizer::optimize (src/optimizer.cpp:448-449): scenes whose solve was
+ * usable (status != SMPC_FAILURE; the reference returns before the store otherwise, :384-388) keep the optimised path
+ * and commands for the next call. path / cmds / status are smpc_result_batch arrays. */
+int smpc_memory_store_batch(smpc_handle* h, int32_t B, int32_t T, int32_t on_device, const int32_t* status,
+                            const double* path, const double* cmds, smpc_memory_batch* memory);
 
 /* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
  * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */

@@ -6,7 +6,7 @@ Struct layouts must stay in lock-step with include/smpc.h (checked by tests/test
 """
 import ctypes as C
 
-SMPC_ABI_VERSION = 1
+SMPC_ABI_VERSION = 2
 SMPC_MAX_BLOCKS = 10
 
 # enum smpc_linear_solver (mirrors OptimizerParams::solver_types, reference optimizer.hpp:71-77)
@@ -96,6 +96,39 @@ class SmpcProjectionBatch(C.Structure):
     ]
 
 
+class SmpcMemoryBatch(C.Structure):
+    _fields_ = [
+        ("prev_path", C.c_void_p),
+        ("prev_cmds", C.c_void_p),
+        ("valid", C.c_void_p),
+    ]
+
+
+class SmpcFormatBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("T", C.c_int32),
+        ("on_device", C.c_int32),
+        ("time_step", C.c_float),
+        ("current_path_w", C.c_float),
+        ("current_cmds_w", C.c_float),
+        ("path", C.c_void_p),
+        ("cmds", C.c_void_p),
+        ("speed", C.c_void_p),
+        ("memory", SmpcMemoryBatch),
+    ]
+
+
+class SmpcFormatOut(C.Structure):
+    _fields_ = [
+        ("robot_status", C.c_void_p),
+        ("pose0", C.c_void_p),
+        ("init_params", C.c_void_p),
+        ("path_pts", C.c_void_p),
+        ("goal_yaw", C.c_void_p),
+    ]
+
+
 class SmpcResultBatch(C.Structure):
     _fields_ = [
         ("params", C.c_void_p),
@@ -129,6 +162,8 @@ EXPORTED_SYMBOLS = [
     "smpc_solve_batch",
     "smpc_eval_batch",
     "smpc_project_people_batch",
+    "smpc_format_to_optimize_batch",
+    "smpc_memory_store_batch",
     "smpc_last_kernel_ms",
     "smpc_last_error",
     "smpc_abi_version",

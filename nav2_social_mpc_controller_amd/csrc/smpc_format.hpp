@@ -1,0 +1,110 @@
+// smpc_format.hpp — SURVEY §8 row f2 on the device: Optimizer::format_to_optimize (reference src/optimizer.cpp:484-551)
+// and the TrajectoryMemory store (:448-449) for B scenes, plus the solve inputs Optimizer::optimize derives from the
+// formatted status (:197-261). Elementwise work: one lane per (scene, pose), no cross-lane traffic; HBM-bound
+// (reads 2 x (3 + 2) doubles, writes 6 + 2 (+ 5 into an empty memory record) doubles per pose).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smpc {
+
+struct FormatParams {
+  int B, T, nb, P;
+  float time_step, current_path_w, current_cmds_w;
+  const double* path;   // [B][T+1][3]
+  const double* cmds;   // [B][T+1][2]
+  const double* speed;  // [B][2]
+  double* prev_path;    // [B][T+1][3]
+  double* prev_cmds;    // [B][T+1][2]
+  int32_t* valid;       // [B]
+  double* robot_status; // [B][T+1][6]
+  double* pose0;        // [B][3]
+  double* init_params;  // [B][P]
+  double* path_pts;     // [B][T+1][2]
+  double* goal_yaw;     // [B]
+};
+
+// tf2 Quaternion::setRPY(0, 0, yaw) -> toMsg -> tf2::getYaw for a pure-yaw quaternion (x = y = 0).
+__device__ inline double format_yaw_roundtrip(double yaw) {
+  double sz, cz;
+  sincos(yaw * 0.5, &sz, &cz);
+  return atan2(2.0 * (cz * sz), cz * cz - sz * sz);
+}
+
+// grid: ceil(B * (T + 1) / 256) blocks of 256 lanes; lane = (scene, pose index i)
+__global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Tp = p.T + 1;
+  if (gid >= (long long)p.B * Tp) return;
+  const int s = (int)(gid / Tp), i = (int)(gid - (long long)s * Tp);
+  const size_t e = (size_t)s * Tp + i;
+  const double cx = p.path[3 * e], cy = p.path[3 * e + 1], cyaw = p.path[3 * e + 2];
+  const double cv = p.cmds[2 * e], cw = p.cmds[2 * e + 1];
+  // memory.previous_path.poses.size() == 0: previous := current (:177-183); the blend below then runs against that copy
+  const bool have = p.valid[s] != 0;
+  const double px = have ? p.prev_path[3 * e] : cx, py = have ? p.prev_path[3 * e + 1] : cy;
+  const double pyaw = have ? p.prev_path[3 * e + 2] : cyaw;
+  if (!have) {
+    p.prev_path[3 * e] = cx; p.prev_path[3 * e + 1] = cy; p.prev_path[3 * e + 2] = cyaw;
+    p.prev_cmds[2 * e] = cv; p.prev_cmds[2 * e + 1] = cw;
+  }
+  const double wp = (double)p.current_path_w, wc = (double)p.current_cmds_w;
+  // previous_path is never empty here and holds T + 1 poses, so every pose is blended (:504-520)
+  const double x = wp * cx + (1.0 - wp) * px;
+  const double y = wp * cy + (1.0 - wp) * py;
+  const double yaw = format_yaw_roundtrip(wp * cyaw + (1.0 - wp) * pyaw);
+  double lv, av;
+  if (i == 0) {
+    lv = p.speed[2 * s]; av = p.speed[2 * s + 1];  // :529-533
+  } else {
+    // cmds[i - 1] against previous_cmds[i - 1] (:537-545)
+    const size_t em = e - 1;
+    const double cv1 = p.cmds[2 * em], cw1 = p.cmds[2 * em + 1];
+    const double pv1 = have ? p.prev_cmds[2 * em] : cv1, pw1 = have ? p.prev_cmds[2 * em + 1] : cw1;
+    lv = wc * cv1 + (1.0 - wc) * pv1;
+    av = wc * cw1 + (1.0 - wc) * pw1;
+  }
+  double* r = p.robot_status + 6 * e;
+  r[0] = x; r[1] = y; r[2] = yaw;
+  r[3] = (double)((float)i * p.time_step);  // unsigned * float product (:523)
+  r[4] = lv; r[5] = av;
+  // what Optimizer::optimize takes from optim_status (:206-235, 254-261, 298)
+  p.path_pts[2 * e] = x; p.path_pts[2 * e + 1] = y;
+  if (i == 0) {
+    p.pose0[3 * s] = x; p.pose0[3 * s + 1] = y;
+    p.pose0[3 * s + 2] = format_yaw_roundtrip(yaw);  // evolving_poses[0]: setRPY(0, 0, yaw), read back with getYaw
+  }
+  if (i < p.nb) { p.init_params[(size_t)s * p.P + 2 * i] = lv; p.init_params[(size_t)s * p.P + 2 * i + 1] = av; }
+  if (i == p.T) p.goal_yaw[s] = yaw;
+}
+
+// Second pass of the format step: mark freshly filled memory records valid (after every lane of the first kernel has
+// read the flag).
+__global__ __launch_bounds__(256) void smpc_format_mark_kernel(int B, int32_t* valid) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < B) valid[s] = 1;
+}
+
+struct StoreParams {
+  int B, T;
+  const int32_t* status;
+  const double* path;  // [B][T+1][3] smpc_result_batch.path
+  const double* cmds;  // [B][T+1][2] smpc_result_batch.cmds
+  double* prev_path;
+  double* prev_cmds;
+  int32_t* valid;
+};
+
+__global__ __launch_bounds__(256) void smpc_memory_store_kernel(const StoreParams p) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Tp = p.T + 1;
+  if (gid >= (long long)p.B * Tp) return;
+  const int s = (int)(gid / Tp);
+  if (p.status[s] == 2 /* SMPC_FAILURE */) return;  // the reference returns false before the store (:384-388)
+  const size_t e = (size_t)gid;
+  p.prev_path[3 * e] = p.path[3 * e]; p.prev_path[3 * e + 1] = p.path[3 * e + 1]; p.prev_path[3 * e + 2] = p.path[3 * e + 2];
+  p.prev_cmds[2 * e] = p.cmds[2 * e]; p.prev_cmds[2 * e + 1] = p.cmds[2 * e + 1];
+  if (gid - (long long)s * Tp == 0) p.valid[s] = 1;
+}
+
+}  // namespace smpc

@@ -15,6 +15,7 @@
 
 #include "smpc_lm.hpp"
 #include "smpc_project.hpp"
+#include "smpc_format.hpp"
 
 // ================================================================================================
 // Host side of the C ABI
@@ -390,6 +391,107 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
   if (!in->on_device) {
     SMPC_TRY(down(people_proj, p.people_proj, B * (T + 1) * 6 * N, h->stream));
     SMPC_TRY(down(error, p.error, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
+int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, smpc_format_out* out) {
+  if (!h || !in || !out) { set_error("null handle / input / output"); return SMPC_ERR_INVALID_ARG; }
+  if (in->B < 0 || in->T < 1) { set_error("bad B/T"); return SMPC_ERR_INVALID_ARG; }
+  if (!in->path || !in->cmds || !in->speed || !in->memory.prev_path || !in->memory.prev_cmds || !in->memory.valid) {
+    set_error("null input array / memory record"); return SMPC_ERR_INVALID_ARG;
+  }
+  if (!out->robot_status || !out->pose0 || !out->init_params || !out->path_pts || !out->goal_yaw) {
+    set_error("null output array"); return SMPC_ERR_INVALID_ARG;
+  }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  const Dims d = make_dims(h->prm, in->T, true);
+  const size_t B = in->B, Tp = (size_t)in->T + 1;
+  smpc::FormatParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = in->B; p.T = in->T; p.nb = d.nb; p.P = d.P;
+  p.time_step = in->time_step; p.current_path_w = in->current_path_w; p.current_cmds_w = in->current_cmds_w;
+  Staging st;
+  if (in->on_device) {
+    p.path = in->path; p.cmds = in->cmds; p.speed = in->speed;
+    p.prev_path = in->memory.prev_path; p.prev_cmds = in->memory.prev_cmds; p.valid = in->memory.valid;
+    p.robot_status = out->robot_status; p.pose0 = out->pose0; p.init_params = out->init_params;
+    p.path_pts = out->path_pts; p.goal_yaw = out->goal_yaw;
+  } else {
+    const double* c = nullptr; const int32_t* ci = nullptr;
+    SMPC_TRY(st.up(in->path, B * Tp * 3, &p.path, h->stream));
+    SMPC_TRY(st.up(in->cmds, B * Tp * 2, &p.cmds, h->stream));
+    SMPC_TRY(st.up(in->speed, B * 2, &p.speed, h->stream));
+    SMPC_TRY(st.up(static_cast<const double*>(in->memory.prev_path), B * Tp * 3, &c, h->stream)); p.prev_path = const_cast<double*>(c);
+    SMPC_TRY(st.up(static_cast<const double*>(in->memory.prev_cmds), B * Tp * 2, &c, h->stream)); p.prev_cmds = const_cast<double*>(c);
+    SMPC_TRY(st.up(static_cast<const int32_t*>(in->memory.valid), B, &ci, h->stream)); p.valid = const_cast<int32_t*>(ci);
+    SMPC_TRY(st.out(out->robot_status, B * Tp * 6, &p.robot_status));
+    SMPC_TRY(st.out(out->pose0, B * 3, &p.pose0));
+    SMPC_TRY(st.out(out->init_params, B * (size_t)d.P, &p.init_params));
+    SMPC_TRY(st.out(out->path_pts, B * Tp * 2, &p.path_pts));
+    SMPC_TRY(st.out(out->goal_yaw, B, &p.goal_yaw));
+  }
+  if (B > 0) {
+    const long long n = (long long)B * (long long)Tp;
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_format_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(smpc::smpc_format_mark_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (int)B, p.valid);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!in->on_device) {
+    SMPC_TRY(down(out->robot_status, p.robot_status, B * Tp * 6, h->stream));
+    SMPC_TRY(down(out->pose0, p.pose0, B * 3, h->stream));
+    SMPC_TRY(down(out->init_params, p.init_params, B * (size_t)d.P, h->stream));
+    SMPC_TRY(down(out->path_pts, p.path_pts, B * Tp * 2, h->stream));
+    SMPC_TRY(down(out->goal_yaw, p.goal_yaw, B, h->stream));
+    SMPC_TRY(down(in->memory.prev_path, p.prev_path, B * Tp * 3, h->stream));
+    SMPC_TRY(down(in->memory.prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
+    SMPC_TRY(down(in->memory.valid, p.valid, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
+int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_device, const int32_t* status,
+                            const double* path, const double* cmds, smpc_memory_batch* memory) {
+  if (!h || !status || !path || !cmds || !memory || !memory->prev_path || !memory->prev_cmds || !memory->valid) {
+    set_error("null handle / array / memory record"); return SMPC_ERR_INVALID_ARG;
+  }
+  if (B_ < 0 || T < 1) { set_error("bad B/T"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t B = B_, Tp = (size_t)T + 1;
+  smpc::StoreParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = B_; p.T = T;
+  Staging st;
+  if (on_device) {
+    p.status = status; p.path = path; p.cmds = cmds;
+    p.prev_path = memory->prev_path; p.prev_cmds = memory->prev_cmds; p.valid = memory->valid;
+  } else {
+    const double* c = nullptr; const int32_t* ci = nullptr;
+    SMPC_TRY(st.up(status, B, &p.status, h->stream));
+    SMPC_TRY(st.up(path, B * Tp * 3, &p.path, h->stream));
+    SMPC_TRY(st.up(cmds, B * Tp * 2, &p.cmds, h->stream));
+    SMPC_TRY(st.up(static_cast<const double*>(memory->prev_path), B * Tp * 3, &c, h->stream)); p.prev_path = const_cast<double*>(c);
+    SMPC_TRY(st.up(static_cast<const double*>(memory->prev_cmds), B * Tp * 2, &c, h->stream)); p.prev_cmds = const_cast<double*>(c);
+    SMPC_TRY(st.up(static_cast<const int32_t*>(memory->valid), B, &ci, h->stream)); p.valid = const_cast<int32_t*>(ci);
+  }
+  if (B > 0) {
+    const long long n = (long long)B * (long long)Tp;
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_memory_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!on_device) {
+    SMPC_TRY(down(memory->prev_path, p.prev_path, B * Tp * 3, h->stream));
+    SMPC_TRY(down(memory->prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
+    SMPC_TRY(down(memory->valid, p.valid, B, h->stream));
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   return SMPC_OK;

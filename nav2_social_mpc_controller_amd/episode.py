@@ -1,0 +1,185 @@
+"""Closed-loop (receding-horizon) batch episodes: B independent robots, every tick runs the whole
+`Optimizer::optimize` chain of the reference on the device,
+
+    format_to_optimize + TrajectoryMemory   (src/optimizer.cpp:172-190, 484-551)  -> smpc_format_to_optimize_batch
+    project_people                           (src/optimizer.cpp:554-728)           -> smpc_project_people_batch
+    problem assembly + ceres::Solve + unpack (src/optimizer.cpp:197-446)           -> smpc_solve_batch
+    memory store                             (src/optimizer.cpp:448-449)           -> smpc_memory_store_batch
+
+with all state resident in HBM (torch tensors are only the allocator here). What the reference gets from outside its
+optimiser is stood in for by the simplest thing that has the same shape:
+  * the trajectorizer path / cmds (not built): a constant-curvature arc from the current pose;
+  * the world: the robot moves to the first pose of the optimised path and takes its first command as current twist,
+    people move with constant velocity.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._abi import SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcProjectionBatch, SmpcSceneBatch
+from .params import OptimizerParams
+from .scenes import SceneBatch
+from .solver import BatchSolver
+
+
+@dataclass
+class TickRecord:
+    """Host copies of one tick's intermediate results (only filled when `record=True`; tests replay them on the CPU)."""
+    plan_path: np.ndarray
+    plan_cmds: np.ndarray
+    speed: np.ndarray
+    init_people: np.ndarray
+    memory_before: dict
+    robot_status: np.ndarray
+    pose0: np.ndarray
+    init_params: np.ndarray
+    path_pts: np.ndarray
+    goal_yaw: np.ndarray
+    people_proj: np.ndarray
+    proj_error: np.ndarray
+    result: dict
+    memory_after: dict
+
+
+class BatchEpisode:
+    def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
+                 od_origin: np.ndarray, od_resolution: float, device: int = 0):
+        """scenes: the start state (pose0, people at step 0, costmaps); w_ref [B]: curvature of the plan stand-in;
+        od_*: one ObstacleDistance grid shared by all scenes."""
+        import torch
+
+        self.torch = torch
+        self.params = params
+        self.solver = BatchSolver(params, device)
+        self.dev = f"cuda:{device}"
+        B, T, N = scenes.B, scenes.T, scenes.N
+        self.B, self.T, self.N = B, T, N
+        CH, bl, nb, P, M, _ = params.dims(T, True)
+        self.P = P
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.pose = torch.from_numpy(scenes.pose0.copy()).to(self.dev)                 # [B,3] current robot pose
+        self.speed = torch.from_numpy(scenes.init_params[:, 0:2].copy()).to(self.dev)  # [B,2] current twist
+        self.w_ref = torch.from_numpy(np.ascontiguousarray(w_ref, np.float64)).to(self.dev)
+        # people_to_status layout [B,N,6]: x, y, yaw, t, lv, av (scene people at step 0)
+        self.people = torch.from_numpy(np.ascontiguousarray(scenes.people[:, 0].transpose(0, 2, 1))).to(self.dev)
+        self.has_people = torch.from_numpy(scenes.has_people.copy()).to(self.dev)
+        self.costmap = torch.from_numpy(scenes.costmap).to(self.dev)
+        self.costmap_origin = torch.from_numpy(scenes.costmap_origin).to(self.dev)
+        self.costmap_shared = scenes.costmap_shared
+        self.size_x, self.size_y, self.resolution = scenes.size_x, scenes.size_y, scenes.resolution
+        self.od_indexes = torch.from_numpy(np.ascontiguousarray(od_indexes, np.uint32).view(np.int32)).to(self.dev)
+        self.od_origin = torch.from_numpy(np.ascontiguousarray(od_origin, np.float64).reshape(1, 2)).to(self.dev)
+        self.od_h, self.od_w = int(od_indexes.shape[-2]), int(od_indexes.shape[-1])
+        self.od_resolution = float(od_resolution)
+        # TrajectoryMemory, one record per scene
+        self.mem_path = torch.zeros((B, T + 1, 3), **f64)
+        self.mem_cmds = torch.zeros((B, T + 1, 2), **f64)
+        self.mem_valid = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        # per-tick buffers
+        self.plan_path = torch.zeros((B, T + 1, 3), **f64)
+        self.plan_cmds = torch.zeros((B, T + 1, 2), **f64)
+        self.robot_status = torch.zeros((B, T + 1, 6), **f64)
+        self.pose0 = torch.zeros((B, 3), **f64)
+        self.init_params = torch.zeros((B, P), **f64)
+        self.path_pts = torch.zeros((B, T + 1, 2), **f64)
+        self.goal_yaw = torch.zeros(B, **f64)
+        self.people_proj = torch.zeros((B, T + 1, 6, N), **f64)
+        self.proj_error = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.rb, self.res = self.solver.alloc_results(B, T, self.dev)
+        self.ticks = 0
+
+    # -- the plan stand-in (row f3 is not built): arc with v = 0.6, w = w_ref from the current pose ---------------
+    def _plan(self):
+        torch = self.torch
+        dt = self.params.dt
+        k = torch.arange(self.T + 1, dtype=torch.float64, device=self.dev)[None, :]
+        th = self.pose[:, 2:3] + self.w_ref[:, None] * dt * k
+        inc = 0.6 * dt * torch.stack([torch.cos(th), torch.sin(th)], dim=-1)           # step k -> k+1
+        xy = self.pose[:, None, 0:2] + torch.cumsum(inc, dim=1) - inc                  # exclusive prefix sum
+        self.plan_path[:, :, 0:2] = xy
+        self.plan_path[:, :, 2] = th
+        self.plan_cmds[:, :, 0] = 0.6
+        self.plan_cmds[:, :, 1] = self.w_ref[:, None]
+
+    def _memory_c(self) -> SmpcMemoryBatch:
+        mb = SmpcMemoryBatch()
+        mb.prev_path, mb.prev_cmds, mb.valid = self.mem_path.data_ptr(), self.mem_cmds.data_ptr(), self.mem_valid.data_ptr()
+        return mb
+
+    def _memory_host(self) -> dict:
+        return {"prev_path": self.mem_path.cpu().numpy().copy(), "prev_cmds": self.mem_cmds.cpu().numpy().copy(),
+                "valid": self.mem_valid.cpu().numpy().copy()}
+
+    def tick(self, record: bool = False):
+        """One controller period for all B robots. Returns a TickRecord when `record`, else None."""
+        torch = self.torch
+        s, prm, B, T, N = self.solver, self.params, self.B, self.T, self.N
+        self._plan()
+        rec = {}
+        if record:
+            rec.update(plan_path=self.plan_path.cpu().numpy().copy(), plan_cmds=self.plan_cmds.cpu().numpy().copy(),
+                       speed=self.speed.cpu().numpy().copy(), init_people=self.people.cpu().numpy().copy(),
+                       memory_before=self._memory_host())
+        # 1. format_to_optimize + memory
+        fb = SmpcFormatBatch()
+        fb.B, fb.T, fb.on_device = B, T, 1
+        fb.time_step = float(prm.dt)
+        fb.current_path_w, fb.current_cmds_w = float(prm.current_path_weight), float(prm.current_cmds_weight)
+        fb.path, fb.cmds, fb.speed = self.plan_path.data_ptr(), self.plan_cmds.data_ptr(), self.speed.data_ptr()
+        fb.memory = self._memory_c()
+        fo = SmpcFormatOut()
+        fo.robot_status, fo.pose0, fo.init_params = self.robot_status.data_ptr(), self.pose0.data_ptr(), self.init_params.data_ptr()
+        fo.path_pts, fo.goal_yaw = self.path_pts.data_ptr(), self.goal_yaw.data_ptr()
+        s.format_device(fb, fo)
+        # 2. project_people
+        pb = SmpcProjectionBatch()
+        pb.B, pb.T, pb.N, pb.on_device = B, T, N, 1
+        pb.max_time, pb.time_step = float(prm.max_time), float(prm.time_step)
+        pb.init_people, pb.robot_path = self.people.data_ptr(), self.robot_status.data_ptr()
+        pb.od_indexes, pb.od_shared = self.od_indexes.data_ptr(), 1
+        pb.od_width, pb.od_height, pb.od_resolution = self.od_w, self.od_h, self.od_resolution
+        pb.od_origin = self.od_origin.data_ptr()
+        s.project_people_device(pb, self.people_proj.data_ptr(), self.proj_error.data_ptr())
+        # 3. solve
+        sb = SmpcSceneBatch()
+        sb.B, sb.T, sb.N, sb.on_device = B, T, N, 1
+        sb.dt = prm.dt
+        sb.pose0, sb.init_params, sb.path_pts = self.pose0.data_ptr(), self.init_params.data_ptr(), self.path_pts.data_ptr()
+        sb.goal_yaw, sb.people, sb.has_people = self.goal_yaw.data_ptr(), self.people_proj.data_ptr(), self.has_people.data_ptr()
+        sb.costmap, sb.costmap_shared = self.costmap.data_ptr(), 1 if self.costmap_shared else 0
+        sb.size_x, sb.size_y = self.size_x, self.size_y
+        sb.costmap_origin, sb.resolution = self.costmap_origin.data_ptr(), self.resolution
+        s.solve_device(sb, self.rb)
+        # 4. memory store (usable solves only)
+        mb = self._memory_c()
+        s.memory_store_device(B, T, self.res["status"].data_ptr(), self.res["path"].data_ptr(), self.res["cmds"].data_ptr(), mb)
+        if record:
+            rec.update(robot_status=self.robot_status.cpu().numpy().copy(), pose0=self.pose0.cpu().numpy().copy(),
+                       init_params=self.init_params.cpu().numpy().copy(), path_pts=self.path_pts.cpu().numpy().copy(),
+                       goal_yaw=self.goal_yaw.cpu().numpy().copy(), people_proj=self.people_proj.cpu().numpy().copy(),
+                       proj_error=self.proj_error.cpu().numpy().copy(),
+                       result={k: v.cpu().numpy().copy() for k, v in self.res.items()}, memory_after=self._memory_host())
+        # 5. the world moves one period: a failed solve keeps the robot where it is with zero twist (the controller's
+        #    fallback publishes a stop, src/social_mpc_controller.cpp:241-245)
+        ok = (self.res["status"] != 2)
+        dt = prm.dt
+        new_pose = self.res["path"][:, 0, :]
+        new_speed = self.res["cmds"][:, 0, :]
+        self.pose = torch.where(ok[:, None], new_pose, self.pose)
+        self.speed = torch.where(ok[:, None], new_speed, torch.zeros_like(self.speed))
+        moving = self.people[:, :, 3] != -1.0
+        step = self.people[:, :, 4] * dt
+        self.people[:, :, 0] += torch.where(moving, step * torch.cos(self.people[:, :, 2]), torch.zeros_like(step))
+        self.people[:, :, 1] += torch.where(moving, step * torch.sin(self.people[:, :, 2]), torch.zeros_like(step))
+        self.ticks += 1
+        return TickRecord(**rec) if record else None
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+
+def far_obstacle_grid(cells: int = 120, resolution: float = 0.1, origin=(-6.0, -6.0)):
+    """An ObstacleDistance grid whose every cell points at one far corner obstacle (valid, but inert for the crowd)."""
+    idx = np.zeros((cells, cells), np.uint32)  # all cells -> cell 0 (the grid corner)
+    return idx, np.asarray(origin, np.float64), float(np.float32(resolution))

@@ -439,3 +439,36 @@ extern "C" int smpc_host_project_people(const double * init_people, int N, const
   }
   return 0;
 }
+
+// Test hook: Optimizer::format_to_optimize for one scene through plain arrays (tests/test_format.py compares it with
+// the numpy restatement and with the device kernel behind smpc_format_to_optimize_batch).
+// path [n][3] (x, y, yaw), cmds [n][2], prev_path [nprev][3], prev_cmds [nprev][2] (nprev = 0: empty memory, which
+// optimize() first fills with the current path / cmds), speed [2]; out [n][6]; returns the number of states written.
+extern "C" int smpc_host_format_to_optimize(const double * path, const double * cmds, int n, const double * prev_path,
+                                            const double * prev_cmds, int nprev, const double * speed,
+                                            float current_path_w, float current_cmds_w, float max_time, float time_step,
+                                            double * out)
+{
+  using namespace nav2_social_mpc_controller;
+  nav_msgs::msg::Path p, pp;
+  std::vector<geometry_msgs::msg::TwistStamped> c(n), pc(nprev);
+  p.poses.resize(n);
+  for (int i = 0; i < n; ++i) {
+    p.poses[i].pose.position.x = path[3 * i]; p.poses[i].pose.position.y = path[3 * i + 1];
+    p.poses[i].pose.orientation = quaternion_from_yaw(path[3 * i + 2]);
+    c[i].twist.linear.x = cmds[2 * i]; c[i].twist.angular.z = cmds[2 * i + 1];
+  }
+  pp.poses.resize(nprev);
+  for (int i = 0; i < nprev; ++i) {
+    pp.poses[i].pose.position.x = prev_path[3 * i]; pp.poses[i].pose.position.y = prev_path[3 * i + 1];
+    pp.poses[i].pose.orientation = quaternion_from_yaw(prev_path[3 * i + 2]);
+    pc[i].twist.linear.x = prev_cmds[2 * i]; pc[i].twist.angular.z = prev_cmds[2 * i + 1];
+  }
+  if (nprev == 0) { pp = p; pc = c; }  // src/optimizer.cpp:177-183
+  geometry_msgs::msg::Twist sp;
+  sp.linear.x = speed[0]; sp.angular.z = speed[1];
+  Optimizer opt;
+  const AgentTrajectory st = opt.format_to_optimize(p, pp, c, pc, sp, current_path_w, current_cmds_w, max_time, time_step);
+  for (size_t i = 0; i < st.size(); ++i) for (int f = 0; f < 6; ++f) out[i * 6 + f] = st[i][f];
+  return (int)st.size();
+}

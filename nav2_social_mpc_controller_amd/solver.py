@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import SmpcEvalOut, SmpcParams, SmpcProjectionBatch, SmpcResultBatch, SmpcSceneBatch
+from ._abi import (SmpcEvalOut, SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcParams, SmpcProjectionBatch,
+                   SmpcResultBatch, SmpcSceneBatch)
 from .params import OptimizerParams
 from .scenes import SceneBatch
 
@@ -33,6 +34,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise SmpcError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback for the solver.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and no longer finds a GPU when it is imported
+    # after this library has initialised /opt/rocm's copy, so when torch is installed it goes first (it is only the
+    # allocator / stream plumbing of the device-resident paths; the host-array paths never touch it).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.smpc_abi_version.restype = C.c_int
     lib.smpc_last_error.restype = C.c_char_p
@@ -52,6 +60,11 @@ def load_library():
     lib.smpc_eval_batch.restype = C.c_int
     lib.smpc_project_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcProjectionBatch), C.c_void_p, C.c_void_p]
     lib.smpc_project_people_batch.restype = C.c_int
+    lib.smpc_format_to_optimize_batch.argtypes = [C.c_void_p, C.POINTER(SmpcFormatBatch), C.POINTER(SmpcFormatOut)]
+    lib.smpc_format_to_optimize_batch.restype = C.c_int
+    lib.smpc_memory_store_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.POINTER(SmpcMemoryBatch)]
+    lib.smpc_memory_store_batch.restype = C.c_int
     lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
     lib.smpc_last_kernel_ms.restype = C.c_double
     if lib.smpc_abi_version() != _abi.SMPC_ABI_VERSION:
@@ -151,6 +164,68 @@ class BatchSolver:
         _check(self.lib, self.lib.smpc_project_people_batch(self._h, C.byref(pb), out.ctypes.data, err.ctypes.data),
                "smpc_project_people_batch")
         return out, err
+
+    # -- warm start / input formatting: format_to_optimize + TrajectoryMemory for B scenes -----
+    def format_to_optimize(self, path: np.ndarray, cmds: np.ndarray, speed: np.ndarray, memory: dict,
+                           current_path_w: float = None, current_cmds_w: float = None):
+        """path [B,T+1,3] (x, y, yaw), cmds [B,T+1,2], speed [B,2]; memory = new_memory(B, T) (updated in place when a
+        record is empty). Returns dict(robot_status [B,T+1,6], pose0, init_params, path_pts, goal_yaw)."""
+        path = np.ascontiguousarray(path, np.float64)
+        cmds = np.ascontiguousarray(cmds, np.float64)
+        speed = np.ascontiguousarray(speed, np.float64)
+        B, Tp, _ = path.shape
+        T = Tp - 1
+        assert cmds.shape == (B, Tp, 2) and speed.shape == (B, 2)
+        assert memory["prev_path"].shape == (B, Tp, 3) and memory["prev_cmds"].shape == (B, Tp, 2)
+        CH, bl, nb, P, M, _ = self.params.dims(T, True)
+        fb = SmpcFormatBatch()
+        fb.B, fb.T, fb.on_device = B, T, 0
+        fb.time_step = float(self.params.dt)
+        fb.current_path_w = float(self.params.current_path_weight if current_path_w is None else current_path_w)
+        fb.current_cmds_w = float(self.params.current_cmds_weight if current_cmds_w is None else current_cmds_w)
+        fb.path, fb.cmds, fb.speed = path.ctypes.data, cmds.ctypes.data, speed.ctypes.data
+        fb.memory.prev_path = memory["prev_path"].ctypes.data
+        fb.memory.prev_cmds = memory["prev_cmds"].ctypes.data
+        fb.memory.valid = memory["valid"].ctypes.data
+        out = {"robot_status": np.zeros((B, Tp, 6)), "pose0": np.zeros((B, 3)), "init_params": np.zeros((B, P)),
+               "path_pts": np.zeros((B, Tp, 2)), "goal_yaw": np.zeros(B)}
+        fo = SmpcFormatOut()
+        for k, v in out.items():
+            setattr(fo, k, v.ctypes.data)
+        _check(self.lib, self.lib.smpc_format_to_optimize_batch(self._h, C.byref(fb), C.byref(fo)),
+               "smpc_format_to_optimize_batch")
+        return out
+
+    @staticmethod
+    def new_memory(B: int, T: int):
+        """An empty TrajectoryMemory record per scene (host arrays)."""
+        return {"prev_path": np.zeros((B, T + 1, 3)), "prev_cmds": np.zeros((B, T + 1, 2)), "valid": np.zeros(B, np.int32)}
+
+    def memory_store(self, status: np.ndarray, path: np.ndarray, cmds: np.ndarray, memory: dict):
+        """The store at the end of Optimizer::optimize: usable solves (status != FAILURE) overwrite their record."""
+        status = np.ascontiguousarray(status, np.int32)
+        path = np.ascontiguousarray(path, np.float64)
+        cmds = np.ascontiguousarray(cmds, np.float64)
+        B, Tp, _ = path.shape
+        mb = SmpcMemoryBatch()
+        mb.prev_path, mb.prev_cmds, mb.valid = (memory["prev_path"].ctypes.data, memory["prev_cmds"].ctypes.data,
+                                                memory["valid"].ctypes.data)
+        _check(self.lib, self.lib.smpc_memory_store_batch(self._h, B, Tp - 1, 0, status.ctypes.data, path.ctypes.data,
+                                                          cmds.ctypes.data, C.byref(mb)), "smpc_memory_store_batch")
+
+    def format_device(self, fb: SmpcFormatBatch, fo: SmpcFormatOut):
+        assert fb.on_device == 1
+        _check(self.lib, self.lib.smpc_format_to_optimize_batch(self._h, C.byref(fb), C.byref(fo)),
+               "smpc_format_to_optimize_batch")
+
+    def memory_store_device(self, B: int, T: int, status_ptr: int, path_ptr: int, cmds_ptr: int, mb: SmpcMemoryBatch):
+        _check(self.lib, self.lib.smpc_memory_store_batch(self._h, B, T, 1, C.c_void_p(status_ptr), C.c_void_p(path_ptr),
+                                                          C.c_void_p(cmds_ptr), C.byref(mb)), "smpc_memory_store_batch")
+
+    def project_people_device(self, pb: SmpcProjectionBatch, out_ptr: int, err_ptr: int):
+        assert pb.on_device == 1
+        _check(self.lib, self.lib.smpc_project_people_batch(self._h, C.byref(pb), C.c_void_p(out_ptr), C.c_void_p(err_ptr)),
+               "smpc_project_people_batch")
 
     # -- device-resident path (inputs already in HBM; asynchronous on the handle's stream) -------
     def alloc_results(self, B: int, T: int, device="cuda:0"):

@@ -1,0 +1,67 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/README or DESIGN.md §oracle): numpy restatement of the reference's warm-start
+formatting, SURVEY §8 row f2. PARITY UNPINNED (the reference holds no fixtures for it; cross-checked against the
+independent C++ restatement in nav2_social_mpc_controller_amd/host/optimizer.cpp by tests/test_format.py).
+
+Follows, per scene:
+  Optimizer::optimize, memory initialisation      reference src/optimizer.cpp:172-186
+  Optimizer::format_to_optimize                   reference src/optimizer.cpp:484-551
+  what optimize() derives from optim_status       reference src/optimizer.cpp:197-261, 298
+  TrajectoryMemory store                          reference src/optimizer.cpp:448-449 (skipped on an unusable solve, :384-388)
+"""
+import math
+
+import numpy as np
+
+
+def yaw_roundtrip(yaw: float) -> float:
+    """tf2::Quaternion::setRPY(0, 0, yaw) -> toMsg -> tf2::getYaw (x = y = 0)."""
+    sz, cz = math.sin(yaw * 0.5), math.cos(yaw * 0.5)
+    return math.atan2(2.0 * (cz * sz), cz * cz - sz * sz)
+
+
+def new_memory(B, T):
+    return {"prev_path": np.zeros((B, T + 1, 3)), "prev_cmds": np.zeros((B, T + 1, 2)), "valid": np.zeros(B, np.int32)}
+
+
+def format_to_optimize(path, cmds, speed, memory, current_path_w, current_cmds_w, time_step, nb):
+    """path [B,T+1,3], cmds [B,T+1,2], speed [B,2]; memory updated in place like the singleton. Plain loops."""
+    path = np.asarray(path, np.float64)
+    cmds = np.asarray(cmds, np.float64)
+    B, Tp, _ = path.shape
+    T = Tp - 1
+    wp = float(np.float32(current_path_w))
+    wc = float(np.float32(current_cmds_w))
+    ts = np.float32(time_step)
+    out = {"robot_status": np.zeros((B, Tp, 6)), "pose0": np.zeros((B, 3)), "init_params": np.zeros((B, 2 * nb)),
+           "path_pts": np.zeros((B, Tp, 2)), "goal_yaw": np.zeros(B)}
+    for s in range(B):
+        if not memory["valid"][s]:  # :177-183
+            memory["prev_path"][s] = path[s]
+            memory["prev_cmds"][s] = cmds[s]
+            memory["valid"][s] = 1
+        pp, pc = memory["prev_path"][s], memory["prev_cmds"][s]
+        for i in range(Tp):
+            x = wp * path[s, i, 0] + (1.0 - wp) * pp[i, 0]
+            y = wp * path[s, i, 1] + (1.0 - wp) * pp[i, 1]
+            yaw = yaw_roundtrip(wp * path[s, i, 2] + (1.0 - wp) * pp[i, 2])
+            if i == 0:
+                lv, av = speed[s, 0], speed[s, 1]
+            else:
+                lv = wc * cmds[s, i - 1, 0] + (1.0 - wc) * pc[i - 1, 0]
+                av = wc * cmds[s, i - 1, 1] + (1.0 - wc) * pc[i - 1, 1]
+            out["robot_status"][s, i] = (x, y, yaw, float(np.float32(i) * ts), lv, av)
+        st = out["robot_status"][s]
+        out["pose0"][s] = (st[0, 0], st[0, 1], yaw_roundtrip(st[0, 2]))
+        for b in range(nb):  # parameter blocks alias optim_velocities[0..nb-1] (:254-261)
+            out["init_params"][s, 2 * b:2 * b + 2] = st[b, 4:6]
+        out["path_pts"][s] = st[:, 0:2]
+        out["goal_yaw"][s] = st[T, 2]
+    return out
+
+
+def memory_store(status, path, cmds, memory):
+    for s in range(len(status)):
+        if status[s] != 2:
+            memory["prev_path"][s] = path[s]
+            memory["prev_cmds"][s] = cmds[s]
+            memory["valid"][s] = 1

@@ -1,0 +1,64 @@
+"""Closed-loop batch episodes (nav2_social_mpc_controller_amd/episode.py): every tick chains the device versions of
+format_to_optimize (f2), project_people (f1) and the solve (a1-a12), then stores the TrajectoryMemory. Each stage of each
+tick is replayed on the CPU from the inputs the device saw (teacher forcing, so errors do not compound over ticks)."""
+import numpy as np
+import pytest
+
+CMD_TOL = 1e-5  # north_star tolerance on the optimised command sequence
+
+
+@pytest.mark.gpu
+def test_episode_ticks_match_cpu_chain(oracle):
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.scenes import SceneBatch, make_scenes, uniform
+    from oracle import pyref_format, pyref_sfm
+
+    prm = OptimizerParams.readme()
+    B, N = 48, 3
+    sc = make_scenes(prm, B, N, n_valid=2)
+    T = sc.T
+    CH, bl, nb, P, M, _ = prm.dims(T, True)
+    w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
+    cells, res, origin = 480, float(np.float32(0.1)), np.array([-16.0, -16.0])
+    od_idx = np.zeros((cells, cells), np.uint32)
+    ep = BatchEpisode(prm, sc, w_ref, od_idx, origin, res)
+    od = dict(width=cells, height=cells, resolution=res, origin_x=origin[0], origin_y=origin[1], indexes=od_idx)
+    n_checked = 0
+    for tick in range(3):
+        r = ep.tick(record=True)
+        # --- f2: format_to_optimize + memory initialisation
+        mem = {k: v.copy() for k, v in r.memory_before.items()}
+        exp = pyref_format.format_to_optimize(r.plan_path, r.plan_cmds, r.speed, mem, prm.current_path_weight,
+                                              prm.current_cmds_weight, prm.time_step, nb)
+        for k in ("robot_status", "pose0", "init_params", "path_pts", "goal_yaw"):
+            err = np.abs(getattr(r, k) - exp[k])
+            err = np.minimum(err, np.abs(err - 2 * np.pi))
+            assert np.max(err) <= 1e-13, (tick, k)
+        assert (r.memory_before["valid"] == (0 if tick == 0 else 1)).all()
+        # --- f1: project_people from the formatted robot status (a few scenes: the numpy restatement is slow)
+        assert (r.proj_error == 0).all()
+        for s in range(0, B, 12):
+            pp = pyref_sfm.project_people(r.init_people[s], r.robot_status[s], od, prm.max_time, prm.time_step,
+                                          theta_zero_convention=True)          # [T+1][N][6]
+            got = r.people_proj[s].transpose(0, 2, 1)                           # [T+1][6][N] -> [T+1][N][6]
+            assert np.max(np.abs(got - pp)) <= 1e-9, (tick, s)
+        # --- a1-a12: the solve on exactly the inputs the device assembled
+        scene = SceneBatch(T, N, prm.dt, r.pose0, r.init_params, r.path_pts, r.goal_yaw,
+                           np.ascontiguousarray(r.people_proj), sc.has_people, sc.costmap, sc.costmap_origin,
+                           sc.resolution, False)
+        rz = oracle.solve(prm, scene, nthreads=8, theta_zero_convention=True)
+        firm = rz["marginal_decisions"] == 0
+        assert firm.mean() >= 0.8
+        err = np.max(np.abs(r.result["cmds"] - rz["cmds"]).reshape(B, -1), axis=1)
+        assert np.max(err[firm]) <= CMD_TOL, (tick, float(np.max(err[firm])))
+        assert np.array_equal(r.result["status"][firm], rz["status"][firm])
+        n_checked += int(firm.sum())
+        # --- memory store: usable solves overwrite their record with the optimised path / cmds
+        ok = r.result["status"] != 2
+        assert np.array_equal(r.memory_after["prev_path"][ok], r.result["path"][ok])
+        assert np.array_equal(r.memory_after["prev_cmds"][ok], r.result["cmds"][ok])
+        assert (r.memory_after["valid"] == 1).all()
+    assert n_checked >= 100
+    # the robots actually moved: closed loop, not three solves of the same scene
+    assert np.max(np.abs(ep.pose.cpu().numpy()[:, :2] - sc.pose0[:, :2])) > 0.02

@@ -1,0 +1,143 @@
+"""Warm start / input formatting: Optimizer::format_to_optimize + TrajectoryMemory. Three statements
+are compared: oracle/pyref_format.py (numpy, the checker), the C++ host adapter (CPU) and the HIP kernels behind
+smpc_format_to_optimize_batch / smpc_memory_store_batch (GPU). PARITY UNPINNED: the reference holds no fixtures for it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "nav2_social_mpc_controller_amd", "host")
+
+
+def make_inputs(seed, B, T):
+    rng = np.random.default_rng(seed)
+    path = np.zeros((B, T + 1, 3))
+    path[:, :, 0:2] = rng.uniform(-5, 5, size=(B, 1, 2)) + np.cumsum(rng.uniform(-0.03, 0.03, size=(B, T + 1, 2)), axis=1)
+    path[:, :, 2] = rng.uniform(-np.pi, np.pi, size=(B, 1)) + np.cumsum(rng.uniform(-0.03, 0.03, size=(B, T + 1)), axis=1)
+    cmds = np.stack([rng.uniform(0, 0.6, size=(B, T + 1)), rng.uniform(-1, 1, size=(B, T + 1))], axis=-1)
+    speed = np.stack([rng.uniform(0, 0.6, size=B), rng.uniform(-1, 1, size=B)], axis=-1)
+    return path, cmds, speed
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    lib = C.CDLL(os.path.join(HOST, "libsmpc_host.so"))
+    lib.smpc_host_format_to_optimize.restype = C.c_int
+    lib.smpc_host_format_to_optimize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    return lib
+
+
+def host_format(lib, path, cmds, prev_path, prev_cmds, speed, wp, wc, max_time, dt):
+    n = path.shape[0]
+    out = np.zeros((n, 6))
+    nprev = 0 if prev_path is None else prev_path.shape[0]
+    pp = np.zeros((1, 3)) if prev_path is None else np.ascontiguousarray(prev_path)
+    pc = np.zeros((1, 2)) if prev_cmds is None else np.ascontiguousarray(prev_cmds)
+    m = lib.smpc_host_format_to_optimize(np.ascontiguousarray(path).ctypes.data, np.ascontiguousarray(cmds).ctypes.data, n,
+                                         pp.ctypes.data, pc.ctypes.data, nprev, np.ascontiguousarray(speed).ctypes.data,
+                                         wp, wc, max_time, dt, out.ctypes.data)
+    return out[:m]
+
+
+@pytest.mark.parametrize("wp,wc", [(1.0, 0.5), (0.7, 0.3), (1.0, 1.0)])
+def test_pyref_matches_host_adapter(hostlib, wp, wc):
+    from oracle import pyref_format
+    B, T, nb = 6, 28, 3
+    path, cmds, speed = make_inputs(1, B, T)
+    prev_path, prev_cmds, _ = make_inputs(2, B, T)
+    mem = pyref_format.new_memory(B, T)
+    mem["prev_path"][3:], mem["prev_cmds"][3:], mem["valid"][3:] = prev_path[3:], prev_cmds[3:], 1  # half the records filled
+    mem0 = {k: v.copy() for k, v in mem.items()}
+    out = pyref_format.format_to_optimize(path, cmds, speed, mem, wp, wc, 0.05, nb)
+    for s in range(B):
+        have = mem0["valid"][s] != 0
+        ref = host_format(hostlib, path[s], cmds[s], mem0["prev_path"][s] if have else None,
+                          mem0["prev_cmds"][s] if have else None, speed[s], wp, wc, 10.0, 0.05)
+        assert ref.shape == (T + 1, 6)
+        assert np.max(np.abs(ref - out["robot_status"][s])) <= 1e-15
+    # an empty record is filled with the incoming path / cmds, a filled one is left alone
+    assert np.array_equal(mem["prev_path"][:3], path[:3]) and np.array_equal(mem["prev_cmds"][:3], cmds[:3])
+    assert np.array_equal(mem["prev_path"][3:], prev_path[3:]) and mem["valid"].tolist() == [1] * B
+    assert np.array_equal(out["path_pts"], out["robot_status"][:, :, 0:2])
+    assert np.array_equal(out["goal_yaw"], out["robot_status"][:, T, 2])
+    assert np.array_equal(out["init_params"].reshape(B, nb, 2), out["robot_status"][:, :nb, 4:6])
+    assert np.array_equal(out["robot_status"][:, 0, 4:6], speed)
+
+
+def test_host_adapter_cut_matches_rollout_steps(hostlib):
+    """format_to_optimize cuts a long path to round(max_time / dt) - 1 poses (src/optimizer.cpp:492-497);
+    OptimizerParams.rollout_steps is that count minus the popped velocity."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    for prm in (OptimizerParams.readme(), OptimizerParams.params_yaml()):
+        n = 80
+        path, cmds, speed = make_inputs(3, 1, n - 1)
+        ref = host_format(hostlib, path[0], cmds[0], None, None, speed[0], 1.0, 1.0, prm.max_time, prm.time_step)
+        assert ref.shape[0] - 1 == prm.rollout_steps
+        short = host_format(hostlib, path[0][:10], cmds[0][:10], None, None, speed[0], 1.0, 1.0, prm.max_time, prm.time_step)
+        assert short.shape[0] == 10
+
+
+def test_pyref_memory_store():
+    from oracle import pyref_format
+    B, T = 5, 8
+    path, cmds, _ = make_inputs(4, B, T)
+    mem = pyref_format.new_memory(B, T)
+    status = np.array([0, 1, 2, 0, 2], np.int32)
+    pyref_format.memory_store(status, path, cmds, mem)
+    assert mem["valid"].tolist() == [1, 1, 0, 1, 0]
+    assert np.array_equal(mem["prev_path"][[0, 1, 3]], path[[0, 1, 3]]) and not mem["prev_path"][[2, 4]].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wp,wc,T", [(1.0, 0.5, 28), (0.7, 0.3, 38), (1.0, 1.0, 5)])
+def test_gpu_format_matches_pyref(wp, wc, T):
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    from oracle import pyref_format
+    prm = OptimizerParams.readme()
+    s = BatchSolver(prm)
+    B = 300
+    CH, bl, nb, P, M, _ = prm.dims(T, True)
+    path, cmds, speed = make_inputs(5, B, T)
+    prev_path, prev_cmds, _ = make_inputs(6, B, T)
+    mem = s.new_memory(B, T)
+    mem["prev_path"][::2], mem["prev_cmds"][::2], mem["valid"][::2] = prev_path[::2], prev_cmds[::2], 1
+    mem_ref = {k: v.copy() for k, v in mem.items()}
+    got = s.format_to_optimize(path, cmds, speed, mem, wp, wc)
+    exp = pyref_format.format_to_optimize(path, cmds, speed, mem_ref, wp, wc, prm.time_step, nb)
+    for k in exp:
+        err = np.abs(got[k] - exp[k])
+        if k in ("robot_status", "pose0", "goal_yaw"):  # yaws: compare on the circle
+            err = np.minimum(err, np.abs(err - 2 * np.pi))
+        assert np.max(err) <= 1e-13, k
+    for k in mem:
+        assert np.array_equal(mem[k], mem_ref[k]), k
+    # second call: every record is now valid and is blended against
+    path2, cmds2, speed2 = make_inputs(7, B, T)
+    got2 = s.format_to_optimize(path2, cmds2, speed2, mem, wp, wc)
+    exp2 = pyref_format.format_to_optimize(path2, cmds2, speed2, mem_ref, wp, wc, prm.time_step, nb)
+    assert np.max(np.abs(got2["robot_status"][:, :, [0, 1, 3, 4, 5]] - exp2["robot_status"][:, :, [0, 1, 3, 4, 5]])) <= 1e-13
+    assert np.array_equal(mem["prev_path"], mem_ref["prev_path"])
+
+
+@pytest.mark.gpu
+def test_gpu_memory_store_matches_pyref():
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    from oracle import pyref_format
+    s = BatchSolver(OptimizerParams.readme())
+    B, T = 257, 28
+    path, cmds, _ = make_inputs(8, B, T)
+    status = np.random.default_rng(9).integers(0, 3, size=B).astype(np.int32)
+    mem = s.new_memory(B, T)
+    mem_ref = {k: v.copy() for k, v in mem.items()}
+    s.memory_store(status, path, cmds, mem)
+    pyref_format.memory_store(status, path, cmds, mem_ref)
+    for k in mem:
+        assert np.array_equal(mem[k], mem_ref[k]), k
+    assert (status == 2).any() and (mem["valid"] == (status != 2)).all()

@@ -1,0 +1,26 @@
+"""Development probe: closed-loop batch episode throughput (format + project + solve + store per tick)."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from nav2_social_mpc_controller_amd.episode import BatchEpisode
+from nav2_social_mpc_controller_amd.params import OptimizerParams
+from nav2_social_mpc_controller_amd.scenes import make_scenes, uniform
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+prm = OptimizerParams.readme()
+sc = make_scenes(prm, B, N)
+w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
+ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1)
+for _ in range(2):
+    ep.tick()
+ep.synchronize()
+t0 = time.perf_counter()
+for _ in range(ticks):
+    ep.tick()
+ep.synchronize()
+dt = (time.perf_counter() - t0) / ticks
+st = ep.res["status"].cpu().numpy()
+print(f"episode B={B} N={N}: {dt*1e3:.3f} ms/tick -> {B/dt:.0f} controller ticks/s; last-tick status {np.bincount(st, minlength=3)} "
+      f"iters mean {ep.res['iterations'].double().mean().item():.1f} sweeps mean {ep.res['evaluations'].double().mean().item():.1f}; proj errors {(ep.proj_error != 0).sum().item()}")
