@@ -213,13 +213,15 @@ typedef struct smpc_memory_batch {
  * record first store the incoming path / cmds in it (:177-183) and then blend with that copy, like the reference. */
 typedef struct smpc_format_batch {
   int32_t B;
-  int32_t T;          /* path has T + 1 poses */
+  int32_t T;          /* T + 1 poses of every path are formatted */
+  int32_t path_rows;  /* row stride of `path` / `cmds` in poses (0: T + 1) — e.g. max_steps + 1 when they come straight from
+                         smpc_trajectorize_path_batch and T + 1 is the cut length */
   int32_t on_device;  /* 0: host pointers (memory record included), 1: device pointers; outputs follow */
   float time_step;
   float current_path_w; /* OptimizerParams::current_path_w / current_cmds_w (optimizer.hpp:93-94, floats) */
   float current_cmds_w;
-  const double* path;  /* [B][T+1][3] x, y, tf2::getYaw(orientation) of the trajectorizer path */
-  const double* cmds;  /* [B][T+1][2] trajectorizer commands (entries 0..T-1 are read) */
+  const double* path;  /* [B][path_rows][3] x, y, tf2::getYaw(orientation) of the trajectorizer path */
+  const double* cmds;  /* [B][path_rows][2] trajectorizer commands (entries 0..T are read; T only to seed an empty memory) */
   const double* speed; /* [B][2] current robot twist linear.x, angular.z */
   smpc_memory_batch memory;
 } smpc_format_batch;
@@ -239,6 +241,43 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
  * and commands for the next call. path / cmds / status are smpc_result_batch arrays. */
 int smpc_memory_store_batch(smpc_handle* h, int32_t B, int32_t T, int32_t on_device, const int32_t* status,
                             const double* path, const double* cmds, smpc_memory_batch* memory);
+
+/* ---- initial-guess generator -------------------------------------------------------------------
+ * PathTrajectorizer::trajectorize (src/path_trajectorizer.cpp:120-288; motion model path_trajectorizer.hpp:106-135)
+ * for B global plans: pure-pursuit simulation from the robot pose until the plan's last pose is within 0.2 m or
+ * max_steps steps were taken. Parameters mirror PathTrajectorizer::configure (src/path_trajectorizer.cpp:53-84). */
+enum smpc_trajectorize_error {
+  SMPC_TRAJ_OK = 0,
+  SMPC_TRAJ_SHORT_PLAN = 1,  /* fewer than 2 poses: trajectorize returns false (:123-127); n_poses = 0 */
+  SMPC_TRAJ_NO_WAYPOINT = 2  /* every plan pose farther than 100 m and outside the look-ahead circle: the reference
+                                indexes poses[-1] (:160-178); the simulation stops at the step it happens */
+};
+
+typedef struct smpc_trajectorize_batch {
+  int32_t B;
+  int32_t L;          /* row stride of `plan`: the longest plan, in poses */
+  int32_t max_steps;  /* (int)round(max_time / time_step) (:84) */
+  int32_t on_device;  /* 0: host pointers, 1: device pointers (outputs follow) */
+  int32_t omnidirectional;
+  double desired_linear_vel; /* defaults 0.4, 0.4, 1.0, 0.05 (:53-60) */
+  double lookahead_dist;
+  double max_angular_vel;
+  double time_step;
+  const double* plan;        /* [B][L][2] plan pose positions, in the frame of robot_pose */
+  const int32_t* plan_len;   /* [B] poses of each plan */
+  const double* robot_pose;  /* [B][3] x, y, tf2::getYaw(orientation) */
+} smpc_trajectorize_batch;
+
+typedef struct smpc_trajectorize_out {
+  double* path;     /* [B][max_steps+1][3] x, y, yaw as tf2::getYaw reads the stored orientation; pose 0 = robot pose;
+                       same layout as smpc_format_batch.path */
+  double* cmds;     /* [B][max_steps+1][2] linear.x, angular.z of every step taken; same layout as smpc_format_batch.cmds */
+  double* cmds_vy;  /* [B][max_steps+1] linear.y (non-zero for omnidirectional only); may be NULL */
+  int32_t* n_poses; /* [B] poses written = steps taken + 1; rows beyond are zero */
+  int32_t* error;   /* [B] enum smpc_trajectorize_error; may be NULL */
+} smpc_trajectorize_out;
+
+int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* in, smpc_trajectorize_out* out);
 
 /* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
  * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */

@@ -108,6 +108,7 @@ class SmpcFormatBatch(C.Structure):
     _fields_ = [
         ("B", C.c_int32),
         ("T", C.c_int32),
+        ("path_rows", C.c_int32),
         ("on_device", C.c_int32),
         ("time_step", C.c_float),
         ("current_path_w", C.c_float),
@@ -126,6 +127,33 @@ class SmpcFormatOut(C.Structure):
         ("init_params", C.c_void_p),
         ("path_pts", C.c_void_p),
         ("goal_yaw", C.c_void_p),
+    ]
+
+
+class SmpcTrajectorizeBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("L", C.c_int32),
+        ("max_steps", C.c_int32),
+        ("on_device", C.c_int32),
+        ("omnidirectional", C.c_int32),
+        ("desired_linear_vel", C.c_double),
+        ("lookahead_dist", C.c_double),
+        ("max_angular_vel", C.c_double),
+        ("time_step", C.c_double),
+        ("plan", C.c_void_p),
+        ("plan_len", C.c_void_p),
+        ("robot_pose", C.c_void_p),
+    ]
+
+
+class SmpcTrajectorizeOut(C.Structure):
+    _fields_ = [
+        ("path", C.c_void_p),
+        ("cmds", C.c_void_p),
+        ("cmds_vy", C.c_void_p),
+        ("n_poses", C.c_void_p),
+        ("error", C.c_void_p),
     ]
 
 
@@ -164,6 +192,7 @@ EXPORTED_SYMBOLS = [
     "smpc_project_people_batch",
     "smpc_format_to_optimize_batch",
     "smpc_memory_store_batch",
+    "smpc_trajectorize_path_batch",
     "smpc_last_kernel_ms",
     "smpc_last_error",
     "smpc_abi_version",

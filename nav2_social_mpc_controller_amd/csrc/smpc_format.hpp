@@ -9,7 +9,7 @@
 namespace smpc {
 
 struct FormatParams {
-  int B, T, nb, P;
+  int B, T, nb, P, rows;  // rows: pose stride of path / cmds
   float time_step, current_path_w, current_cmds_w;
   const double* path;   // [B][T+1][3]
   const double* cmds;   // [B][T+1][2]
@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) 
   const int Tp = p.T + 1;
   if (gid >= (long long)p.B * Tp) return;
   const int s = (int)(gid / Tp), i = (int)(gid - (long long)s * Tp);
-  const size_t e = (size_t)s * Tp + i;
-  const double cx = p.path[3 * e], cy = p.path[3 * e + 1], cyaw = p.path[3 * e + 2];
-  const double cv = p.cmds[2 * e], cw = p.cmds[2 * e + 1];
+  const size_t e = (size_t)s * Tp + i;          // element of the dense [B][T+1] arrays
+  const size_t ei = (size_t)s * p.rows + i;      // element of the incoming path / cmds
+  const double cx = p.path[3 * ei], cy = p.path[3 * ei + 1], cyaw = p.path[3 * ei + 2];
+  const double cv = p.cmds[2 * ei], cw = p.cmds[2 * ei + 1];
   // memory.previous_path.poses.size() == 0: previous := current (:177-183); the blend below then runs against that copy
   const bool have = p.valid[s] != 0;
   const double px = have ? p.prev_path[3 * e] : cx, py = have ? p.prev_path[3 * e + 1] : cy;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) 
   } else {
     // cmds[i - 1] against previous_cmds[i - 1] (:537-545)
     const size_t em = e - 1;
-    const double cv1 = p.cmds[2 * em], cw1 = p.cmds[2 * em + 1];
+    const double cv1 = p.cmds[2 * (ei - 1)], cw1 = p.cmds[2 * (ei - 1) + 1];
     const double pv1 = have ? p.prev_cmds[2 * em] : cv1, pw1 = have ? p.prev_cmds[2 * em + 1] : cw1;
     lv = wc * cv1 + (1.0 - wc) * pv1;
     av = wc * cw1 + (1.0 - wc) * pw1;

@@ -16,6 +16,7 @@
 #include "smpc_lm.hpp"
 #include "smpc_project.hpp"
 #include "smpc_format.hpp"
+#include "smpc_trajectorize.hpp"
 
 // ================================================================================================
 // Host side of the C ABI
@@ -410,7 +411,9 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
   const size_t B = in->B, Tp = (size_t)in->T + 1;
   smpc::FormatParams p;
   std::memset(&p, 0, sizeof(p));
-  p.B = in->B; p.T = in->T; p.nb = d.nb; p.P = d.P;
+  const size_t rows = in->path_rows > 0 ? (size_t)in->path_rows : Tp;
+  if (rows < Tp) { set_error("path_rows < T + 1"); return SMPC_ERR_INVALID_ARG; }
+  p.B = in->B; p.T = in->T; p.nb = d.nb; p.P = d.P; p.rows = (int)rows;
   p.time_step = in->time_step; p.current_path_w = in->current_path_w; p.current_cmds_w = in->current_cmds_w;
   Staging st;
   if (in->on_device) {
@@ -420,8 +423,8 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
     p.path_pts = out->path_pts; p.goal_yaw = out->goal_yaw;
   } else {
     const double* c = nullptr; const int32_t* ci = nullptr;
-    SMPC_TRY(st.up(in->path, B * Tp * 3, &p.path, h->stream));
-    SMPC_TRY(st.up(in->cmds, B * Tp * 2, &p.cmds, h->stream));
+    SMPC_TRY(st.up(in->path, B * rows * 3, &p.path, h->stream));
+    SMPC_TRY(st.up(in->cmds, B * rows * 2, &p.cmds, h->stream));
     SMPC_TRY(st.up(in->speed, B * 2, &p.speed, h->stream));
     SMPC_TRY(st.up(static_cast<const double*>(in->memory.prev_path), B * Tp * 3, &c, h->stream)); p.prev_path = const_cast<double*>(c);
     SMPC_TRY(st.up(static_cast<const double*>(in->memory.prev_cmds), B * Tp * 2, &c, h->stream)); p.prev_cmds = const_cast<double*>(c);
@@ -492,6 +495,51 @@ int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_de
     SMPC_TRY(down(memory->prev_path, p.prev_path, B * Tp * 3, h->stream));
     SMPC_TRY(down(memory->prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
     SMPC_TRY(down(memory->valid, p.valid, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
+int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* in, smpc_trajectorize_out* out) {
+  if (!h || !in || !out) { set_error("null handle / input / output"); return SMPC_ERR_INVALID_ARG; }
+  if (in->B < 0 || in->L < 1 || in->max_steps < 0) { set_error("bad B / L / max_steps"); return SMPC_ERR_INVALID_ARG; }
+  if (!in->plan || !in->plan_len || !in->robot_pose) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
+  if (!out->path || !out->cmds || !out->n_poses) { set_error("null output array"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t B = in->B, L = in->L, S1 = (size_t)in->max_steps + 1;
+  smpc::TrajParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = in->B; p.L = in->L; p.max_steps = in->max_steps; p.omnidirectional = in->omnidirectional;
+  p.desired_linear_vel = in->desired_linear_vel; p.lookahead_dist = in->lookahead_dist;
+  p.max_angular_vel = in->max_angular_vel; p.time_step = in->time_step;
+  Staging st;
+  if (in->on_device) {
+    p.plan = in->plan; p.plan_len = in->plan_len; p.robot_pose = in->robot_pose;
+    p.path = out->path; p.cmds = out->cmds; p.cmds_vy = out->cmds_vy; p.n_poses = out->n_poses; p.error = out->error;
+  } else {
+    SMPC_TRY(st.up(in->plan, B * L * 2, &p.plan, h->stream));
+    SMPC_TRY(st.up(in->plan_len, B, &p.plan_len, h->stream));
+    SMPC_TRY(st.up(in->robot_pose, B * 3, &p.robot_pose, h->stream));
+    SMPC_TRY(st.out(out->path, B * S1 * 3, &p.path));
+    SMPC_TRY(st.out(out->cmds, B * S1 * 2, &p.cmds));
+    SMPC_TRY(st.out(out->cmds_vy, B * S1, &p.cmds_vy));
+    SMPC_TRY(st.out(out->n_poses, B, &p.n_poses));
+    SMPC_TRY(st.out(out->error, B, &p.error));
+  }
+  if (B > 0) {
+    const int per_wave = smpc::kWave / smpc::kTrajGroup;
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel, dim3((unsigned)((B + per_wave - 1) / per_wave)), dim3(smpc::kWave), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!in->on_device) {
+    SMPC_TRY(down(out->path, p.path, B * S1 * 3, h->stream));
+    SMPC_TRY(down(out->cmds, p.cmds, B * S1 * 2, h->stream));
+    SMPC_TRY(down(out->cmds_vy, p.cmds_vy, B * S1, h->stream));
+    SMPC_TRY(down(out->n_poses, p.n_poses, B, h->stream));
+    SMPC_TRY(down(out->error, p.error, B, h->stream));
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   return SMPC_OK;

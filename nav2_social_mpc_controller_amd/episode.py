@@ -6,9 +6,11 @@
     problem assembly + ceres::Solve + unpack (src/optimizer.cpp:197-446)           -> smpc_solve_batch
     memory store                             (src/optimizer.cpp:448-449)           -> smpc_memory_store_batch
 
-with all state resident in HBM (torch tensors are only the allocator here). What the reference gets from outside its
-optimiser is stood in for by the simplest thing that has the same shape:
-  * the trajectorizer path / cmds (SURVEY §8 row f3, not built): a constant-curvature arc from the current pose;
+preceded, when global plans are given, by PathTrajectorizer::trajectorize (src/path_trajectorizer.cpp:120-288 ->
+smpc_trajectorize_path_batch) as in SocialMPCController::computeVelocityCommands (src/social_mpc_controller.cpp:176-189),
+with all state resident in HBM (torch tensors are only the allocator here). What the reference gets from outside is
+stood in for by the simplest thing that has the same shape:
+  * without global plans: a constant-curvature arc from the current pose in place of the trajectorizer output;
   * the world: the robot moves to the first pose of the optimised path and takes its first command as current twist,
     people move with constant velocity.
 """
@@ -17,8 +19,9 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from ._abi import SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcProjectionBatch, SmpcSceneBatch
-from .params import OptimizerParams
+from ._abi import (SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcProjectionBatch, SmpcSceneBatch,
+                   SmpcTrajectorizeOut)
+from .params import OptimizerParams, TrajectorizerParams
 from .scenes import SceneBatch
 from .solver import BatchSolver
 
@@ -40,19 +43,25 @@ class TickRecord:
     proj_error: np.ndarray
     result: dict
     memory_after: dict
+    robot_pose: np.ndarray = None   # [B,3] pose the trajectorizer started from (plan mode)
+    traj_n_poses: np.ndarray = None
 
 
 class BatchEpisode:
     def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
-                 od_origin: np.ndarray, od_resolution: float, device: int = 0):
-        """scenes: the start state (pose0, people at step 0, costmaps); w_ref [B]: curvature of the plan stand-in;
-        od_*: one ObstacleDistance grid shared by all scenes."""
+                 od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
+                 plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None):
+        """scenes: the start state (pose0, people at step 0, costmaps); w_ref [B]: curvature of the arc stand-in;
+        od_*: one ObstacleDistance grid shared by all scenes. plan [B,L,2] + plan_len [B] + traj_params: global plans,
+        trajectorized on the device every tick (the plan must stay longer than the horizon for the whole episode)."""
         import torch
 
         self.torch = torch
         self.params = params
         self.solver = BatchSolver(params, device)
         self.dev = f"cuda:{device}"
+        # library kernels and the few torch ops of the world model share one stream, so they are ordered
+        self.solver.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         B, T, N = scenes.B, scenes.T, scenes.N
         self.B, self.T, self.N = B, T, N
         CH, bl, nb, P, M, _ = params.dims(T, True)
@@ -77,8 +86,20 @@ class BatchEpisode:
         self.mem_cmds = torch.zeros((B, T + 1, 2), **f64)
         self.mem_valid = torch.zeros(B, dtype=torch.int32, device=self.dev)
         # per-tick buffers
-        self.plan_path = torch.zeros((B, T + 1, 3), **f64)
-        self.plan_cmds = torch.zeros((B, T + 1, 2), **f64)
+        self.traj = traj_params
+        if plan is not None:
+            assert traj_params is not None and traj_params.max_steps >= T
+            self.plan = torch.from_numpy(np.ascontiguousarray(plan, np.float64)).to(self.dev)
+            self.plan_len = torch.from_numpy(np.ascontiguousarray(plan_len, np.int32)).to(self.dev)
+            self.rows = traj_params.max_steps + 1
+            self.traj_n = torch.zeros(B, dtype=torch.int32, device=self.dev)
+            self.traj_err = torch.zeros(B, dtype=torch.int32, device=self.dev)
+            self.traj_vy = torch.zeros((B, self.rows), **f64)
+        else:
+            self.plan = None
+            self.rows = T + 1
+        self.plan_path = torch.zeros((B, self.rows, 3), **f64)
+        self.plan_cmds = torch.zeros((B, self.rows, 2), **f64)
         self.robot_status = torch.zeros((B, T + 1, 6), **f64)
         self.pose0 = torch.zeros((B, 3), **f64)
         self.init_params = torch.zeros((B, P), **f64)
@@ -89,9 +110,17 @@ class BatchEpisode:
         self.rb, self.res = self.solver.alloc_results(B, T, self.dev)
         self.ticks = 0
 
-    # -- the plan stand-in (row f3 is not built): arc with v = 0.6, w = w_ref from the current pose ---------------
+    # -- trajectorizer (row f3) on the global plans, or the arc stand-in: v = 0.6, w = w_ref from the current pose --
     def _plan(self):
         torch = self.torch
+        if self.plan is not None:
+            tb = self.solver.trajectorize_c(self.traj, self.B, int(self.plan.shape[1]), 1)
+            tb.plan, tb.plan_len, tb.robot_pose = self.plan.data_ptr(), self.plan_len.data_ptr(), self.pose.data_ptr()
+            to = SmpcTrajectorizeOut()
+            to.path, to.cmds, to.cmds_vy = self.plan_path.data_ptr(), self.plan_cmds.data_ptr(), self.traj_vy.data_ptr()
+            to.n_poses, to.error = self.traj_n.data_ptr(), self.traj_err.data_ptr()
+            self.solver.trajectorize_device(tb, to)
+            return
         dt = self.params.dt
         k = torch.arange(self.T + 1, dtype=torch.float64, device=self.dev)[None, :]
         th = self.pose[:, 2:3] + self.w_ref[:, None] * dt * k
@@ -115,15 +144,20 @@ class BatchEpisode:
         """One controller period for all B robots. Returns a TickRecord when `record`, else None."""
         torch = self.torch
         s, prm, B, T, N = self.solver, self.params, self.B, self.T, self.N
+        if not self.pose.is_contiguous():
+            self.pose = self.pose.contiguous()
+        pose_before = self.pose.cpu().numpy().copy() if record else None
         self._plan()
         rec = {}
         if record:
+            if self.plan is not None:
+                rec.update(robot_pose=pose_before, traj_n_poses=self.traj_n.cpu().numpy().copy())
             rec.update(plan_path=self.plan_path.cpu().numpy().copy(), plan_cmds=self.plan_cmds.cpu().numpy().copy(),
                        speed=self.speed.cpu().numpy().copy(), init_people=self.people.cpu().numpy().copy(),
                        memory_before=self._memory_host())
         # 1. format_to_optimize + memory
         fb = SmpcFormatBatch()
-        fb.B, fb.T, fb.on_device = B, T, 1
+        fb.B, fb.T, fb.path_rows, fb.on_device = B, T, self.rows, 1
         fb.time_step = float(prm.dt)
         fb.current_path_w, fb.current_cmds_w = float(prm.current_path_weight), float(prm.current_cmds_weight)
         fb.path, fb.cmds, fb.speed = self.plan_path.data_ptr(), self.plan_cmds.data_ptr(), self.speed.data_ptr()

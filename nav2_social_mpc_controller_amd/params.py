@@ -12,6 +12,22 @@ from ._abi import LINEAR_SOLVER, SmpcParams
 
 
 @dataclass
+class TrajectorizerParams:
+    """`<plugin>.trajectorizer.*` of PathTrajectorizer::configure (src/path_trajectorizer.cpp:53-84), code defaults."""
+    omnidirectional: bool = False
+    desired_linear_vel: float = 0.4
+    lookahead_dist: float = 0.4
+    max_angular_vel: float = 1.0
+    time_step: float = 0.05
+    max_time: float = 3.0
+
+    @property
+    def max_steps(self) -> int:
+        """(int)round(max_time / time_step), doubles (src/path_trajectorizer.cpp:84)."""
+        return int(np.round(self.max_time / self.time_step))
+
+
+@dataclass
 class OptimizerParams:
     # optimizer.* (src/optimizer.cpp:26-55, 76-83)
     linear_solver_type: str = "SPARSE_NORMAL_CHOLESKY"

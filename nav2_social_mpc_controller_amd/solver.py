@@ -13,8 +13,8 @@ import numpy as np
 
 from . import _abi
 from ._abi import (SmpcEvalOut, SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcParams, SmpcProjectionBatch,
-                   SmpcResultBatch, SmpcSceneBatch)
-from .params import OptimizerParams
+                   SmpcResultBatch, SmpcSceneBatch, SmpcTrajectorizeBatch, SmpcTrajectorizeOut)
+from .params import OptimizerParams, TrajectorizerParams
 from .scenes import SceneBatch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -65,6 +65,8 @@ def load_library():
     lib.smpc_memory_store_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.POINTER(SmpcMemoryBatch)]
     lib.smpc_memory_store_batch.restype = C.c_int
+    lib.smpc_trajectorize_path_batch.argtypes = [C.c_void_p, C.POINTER(SmpcTrajectorizeBatch), C.POINTER(SmpcTrajectorizeOut)]
+    lib.smpc_trajectorize_path_batch.restype = C.c_int
     lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
     lib.smpc_last_kernel_ms.restype = C.c_double
     if lib.smpc_abi_version() != _abi.SMPC_ABI_VERSION:
@@ -165,6 +167,38 @@ class BatchSolver:
                "smpc_project_people_batch")
         return out, err
 
+    # -- initial-guess generator: PathTrajectorizer::trajectorize for B plans ------------------
+    @staticmethod
+    def trajectorize_c(tp: TrajectorizerParams, B: int, L: int, on_device: int) -> SmpcTrajectorizeBatch:
+        tb = SmpcTrajectorizeBatch()
+        tb.B, tb.L, tb.max_steps, tb.on_device = B, L, tp.max_steps, on_device
+        tb.omnidirectional = 1 if tp.omnidirectional else 0
+        tb.desired_linear_vel, tb.lookahead_dist = tp.desired_linear_vel, tp.lookahead_dist
+        tb.max_angular_vel, tb.time_step = tp.max_angular_vel, tp.time_step
+        return tb
+
+    def trajectorize(self, tp: TrajectorizerParams, plan: np.ndarray, plan_len: np.ndarray, robot_pose: np.ndarray):
+        """plan [B,L,2], plan_len [B], robot_pose [B,3] (x, y, yaw). Returns dict(path [B,S+1,3], cmds [B,S+1,2],
+        cmds_vy [B,S+1], n_poses [B], error [B]) with S = tp.max_steps."""
+        plan = np.ascontiguousarray(plan, np.float64)
+        plan_len = np.ascontiguousarray(plan_len, np.int32)
+        robot_pose = np.ascontiguousarray(robot_pose, np.float64)
+        B, L, _ = plan.shape
+        tb = self.trajectorize_c(tp, B, L, 0)
+        tb.plan, tb.plan_len, tb.robot_pose = plan.ctypes.data, plan_len.ctypes.data, robot_pose.ctypes.data
+        S1 = tp.max_steps + 1
+        out = {"path": np.zeros((B, S1, 3)), "cmds": np.zeros((B, S1, 2)), "cmds_vy": np.zeros((B, S1)),
+               "n_poses": np.zeros(B, np.int32), "error": np.zeros(B, np.int32)}
+        to = SmpcTrajectorizeOut()
+        for k, v in out.items():
+            setattr(to, k, v.ctypes.data)
+        _check(self.lib, self.lib.smpc_trajectorize_path_batch(self._h, C.byref(tb), C.byref(to)), "smpc_trajectorize_path_batch")
+        return out
+
+    def trajectorize_device(self, tb: SmpcTrajectorizeBatch, to: SmpcTrajectorizeOut):
+        assert tb.on_device == 1
+        _check(self.lib, self.lib.smpc_trajectorize_path_batch(self._h, C.byref(tb), C.byref(to)), "smpc_trajectorize_path_batch")
+
     # -- warm start / input formatting (SURVEY §8 row f2): format_to_optimize + TrajectoryMemory for B scenes -----
     def format_to_optimize(self, path: np.ndarray, cmds: np.ndarray, speed: np.ndarray, memory: dict,
                            current_path_w: float = None, current_cmds_w: float = None):
@@ -179,7 +213,7 @@ class BatchSolver:
         assert memory["prev_path"].shape == (B, Tp, 3) and memory["prev_cmds"].shape == (B, Tp, 2)
         CH, bl, nb, P, M, _ = self.params.dims(T, True)
         fb = SmpcFormatBatch()
-        fb.B, fb.T, fb.on_device = B, T, 0
+        fb.B, fb.T, fb.path_rows, fb.on_device = B, T, Tp, 0
         fb.time_step = float(self.params.dt)
         fb.current_path_w = float(self.params.current_path_weight if current_path_w is None else current_path_w)
         fb.current_cmds_w = float(self.params.current_cmds_weight if current_cmds_w is None else current_cmds_w)

@@ -62,3 +62,59 @@ def test_episode_ticks_match_cpu_chain(oracle):
     assert n_checked >= 100
     # the robots actually moved: closed loop, not three solves of the same scene
     assert np.max(np.abs(ep.pose.cpu().numpy()[:, :2] - sc.pose0[:, :2])) > 0.02
+
+
+def arc_plans(pose0, w_ref, L=400, ds=0.05):
+    """Global plans: constant-curvature arcs of L poses from each robot's start pose."""
+    B = pose0.shape[0]
+    plan = np.zeros((B, L, 2))
+    x, y, th = pose0[:, 0].copy(), pose0[:, 1].copy(), pose0[:, 2].copy()
+    for i in range(L):
+        plan[:, i, 0], plan[:, i, 1] = x, y
+        x, y, th = x + ds * np.cos(th), y + ds * np.sin(th), th + 0.4 * w_ref * ds  # radius >= 4.2 m: the 20 m arc never closes
+    return plan, np.full(B, L, np.int32)
+
+
+@pytest.mark.gpu
+def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
+    """Plan mode: trajectorize (f3) -> format (f2, cut to T + 1 of the max_steps + 1 poses) -> project (f1) -> solve."""
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode
+    from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
+    from nav2_social_mpc_controller_amd.scenes import SceneBatch, make_scenes, uniform
+    from oracle import pyref_format, pyref_trajectorize
+
+    prm = OptimizerParams.readme()
+    tp = TrajectorizerParams(desired_linear_vel=0.6, lookahead_dist=0.4, max_angular_vel=1.0, time_step=0.05, max_time=1.5)
+    B, N = 32, 3
+    sc = make_scenes(prm, B, N, n_valid=2)
+    T = sc.T
+    assert tp.max_steps + 1 > T + 1 == prm.rollout_steps + 1       # the cut of format_to_optimize applies
+    CH, bl, nb, P, M, _ = prm.dims(T, True)
+    w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
+    plan, plan_len = arc_plans(sc.pose0, w_ref)
+    ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)),
+                      plan=plan, plan_len=plan_len, traj_params=tp)
+    for tick in range(3):
+        r = ep.tick(record=True)
+        assert (r.traj_n_poses == tp.max_steps + 1).all()
+        for s in range(0, B, 5):  # f3 on the pose the tick started from
+            p, c, err = pyref_trajectorize.trajectorize(plan[s], r.robot_pose[s], tp.omnidirectional, tp.desired_linear_vel,
+                                                        tp.lookahead_dist, tp.max_angular_vel, tp.time_step, tp.max_time)
+            assert err == 0
+            dyaw = np.abs(r.plan_path[s, :, 2] - p[:, 2])
+            assert np.max(np.abs(r.plan_path[s, :, :2] - p[:, :2])) <= 1e-11 and np.max(np.minimum(dyaw, np.abs(dyaw - 2 * np.pi))) <= 1e-11
+            assert np.max(np.abs(r.plan_cmds[s, :-1] - c[:, [0, 2]])) <= 1e-11
+        mem = {k: v.copy() for k, v in r.memory_before.items()}
+        exp = pyref_format.format_to_optimize(r.plan_path[:, :T + 1], r.plan_cmds[:, :T + 1], r.speed, mem,
+                                              prm.current_path_weight, prm.current_cmds_weight, prm.time_step, nb)
+        for k in ("robot_status", "pose0", "init_params", "path_pts", "goal_yaw"):
+            err = np.abs(getattr(r, k) - exp[k])
+            assert np.max(np.minimum(err, np.abs(err - 2 * np.pi))) <= 1e-13, (tick, k)
+        scene = SceneBatch(T, N, prm.dt, r.pose0, r.init_params, r.path_pts, r.goal_yaw,
+                           np.ascontiguousarray(r.people_proj), sc.has_people, sc.costmap, sc.costmap_origin,
+                           sc.resolution, False)
+        rz = oracle.solve(prm, scene, nthreads=8, theta_zero_convention=True)
+        firm = rz["marginal_decisions"] == 0
+        err = np.max(np.abs(r.result["cmds"] - rz["cmds"]).reshape(B, -1), axis=1)
+        assert firm.mean() >= 0.8 and np.max(err[firm]) <= CMD_TOL, (tick, float(np.max(err[firm])))
+    assert np.max(np.abs(ep.pose.cpu().numpy()[:, :2] - sc.pose0[:, :2])) > 0.02

@@ -1,0 +1,120 @@
+"""Initial-guess generator: PathTrajectorizer::trajectorize. Three statements are compared:
+oracle/pyref_trajectorize.py (plain Python, the checker), the C++ host mirror of the class (CPU) and the HIP kernel
+behind smpc_trajectorize_path_batch (GPU). PARITY UNPINNED: the reference holds no fixtures for it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "nav2_social_mpc_controller_amd", "host")
+
+
+def make_plans(seed, B, L=160):
+    """Global plans: constant-curvature arcs with 0.05-0.1 m spacing; the robot starts near the first pose, sometimes
+    turned away from the plan (rotate-in-place branch), some plans end before max_steps steps (goal reached)."""
+    rng = np.random.default_rng(seed)
+    plan = np.zeros((B, L, 2))
+    plan_len = np.where(rng.uniform(size=B) < 0.25, rng.integers(3, 12, size=B), rng.integers(12, L + 1, size=B)).astype(np.int32)
+    pose = np.zeros((B, 3))
+    for s in range(B):
+        x, y, th = rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi)
+        k, ds = rng.uniform(-0.6, 0.6), rng.uniform(0.05, 0.1)
+        pose[s] = [x + rng.uniform(-0.2, 0.2), y + rng.uniform(-0.2, 0.2),
+                   th + (rng.uniform(-0.5, 0.5) if s % 5 else rng.uniform(2.0, 4.0))]
+        for i in range(plan_len[s]):
+            plan[s, i] = [x, y]
+            x, y, th = x + ds * np.cos(th), y + ds * np.sin(th), th + k * ds
+    return plan, plan_len, pose
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    subprocess.check_call(["make", "-C", HOST, "-s"])
+    lib = C.CDLL(os.path.join(HOST, "libsmpc_host.so"))
+    lib.smpc_host_trajectorize.restype = C.c_int
+    lib.smpc_host_trajectorize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def host_traj(lib, plan, pose, tp):
+    S = tp.max_steps
+    path, cmds = np.zeros((S + 1, 3)), np.zeros((S + 1, 3))
+    plan = np.ascontiguousarray(plan)
+    n = lib.smpc_host_trajectorize(plan.ctypes.data, plan.shape[0], np.ascontiguousarray(pose).ctypes.data,
+                                   1 if tp.omnidirectional else 0, tp.desired_linear_vel, tp.lookahead_dist,
+                                   tp.max_angular_vel, tp.time_step, tp.max_time, path.ctypes.data, cmds.ctypes.data)
+    return path[:n], cmds[:max(n - 1, 0)], n
+
+
+def pyref(plan, pose, tp):
+    from oracle import pyref_trajectorize
+    return pyref_trajectorize.trajectorize(plan, pose, tp.omnidirectional, tp.desired_linear_vel, tp.lookahead_dist,
+                                           tp.max_angular_vel, tp.time_step, tp.max_time)
+
+
+def params(omni=False, **kw):
+    from nav2_social_mpc_controller_amd.params import TrajectorizerParams
+    return TrajectorizerParams(omnidirectional=omni, **kw)
+
+
+@pytest.mark.parametrize("omni", [False, True])
+def test_pyref_matches_host_mirror(hostlib, omni):
+    tp = params(omni, desired_linear_vel=0.6, max_time=1.5)
+    plan, plan_len, pose = make_plans(11, 40)
+    branches = set()
+    for s in range(40):
+        p, c, err = pyref(plan[s, :plan_len[s]], pose[s], tp)
+        hp, hc, n = host_traj(hostlib, plan[s, :plan_len[s]], pose[s], tp)
+        assert err == 0 and n == p.shape[0]
+        assert np.max(np.abs(hp - p)) <= 1e-14 and np.max(np.abs(hc - c)) <= 1e-14
+        branches.add("short" if n < tp.max_steps + 1 else "full")
+        if not omni and (c[:, 0] == 0.0).any():
+            branches.add("rotate")
+    assert {"short", "full"} <= branches and (omni or "rotate" in branches)
+
+
+def test_pyref_edge_cases(hostlib):
+    tp = params()
+    assert pyref(np.zeros((1, 2)), np.zeros(3), tp)[2] == 1          # fewer than two poses: returns false
+    assert host_traj(hostlib, np.zeros((1, 2)), np.zeros(3), tp)[2] == 0
+    far = np.array([[500.0, 0.0], [500.1, 0.0]])
+    p, c, err = pyref(far, np.zeros(3), tp)                           # no candidate way-point (reference: poses[-1])
+    assert err == 2 and p.shape[0] == 1 and c.shape[0] == 0
+    # robot already at the goal: one step is still simulated (goal_dist starts at 1000)
+    near = np.array([[0.0, 0.0], [0.05, 0.0]])
+    p, c, err = pyref(near, np.zeros(3), tp)
+    assert err == 0 and p.shape[0] == 2
+    assert tp.max_steps == 60 and params(time_step=0.05, max_time=1.5).max_steps == 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("omni", [False, True])
+def test_gpu_trajectorize_matches_pyref(omni):
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    tp = params(omni, desired_linear_vel=0.6, max_time=1.5)
+    B = 203
+    plan, plan_len, pose = make_plans(12, B)
+    plan_len[7] = 1                        # SMPC_TRAJ_SHORT_PLAN
+    plan[9, :plan_len[9]] += 1000.0        # SMPC_TRAJ_NO_WAYPOINT
+    s = BatchSolver(OptimizerParams.readme())
+    got = s.trajectorize(tp, plan, plan_len, pose)
+    worst = 0.0
+    for b in range(B):
+        p, c, err = pyref(plan[b, :plan_len[b]], pose[b], tp)
+        assert got["error"][b] == err, b
+        if err == 1:
+            assert got["n_poses"][b] == 0 and not got["path"][b].any()
+            continue
+        n = p.shape[0]
+        assert got["n_poses"][b] == n, (b, got["n_poses"][b], n)
+        dy = np.abs(got["path"][b, :n, 2] - p[:, 2])
+        worst = max(worst, np.max(np.abs(got["path"][b, :n, :2] - p[:, :2])), np.max(np.minimum(dy, np.abs(dy - 2 * np.pi))))
+        if n > 1:
+            worst = max(worst, np.max(np.abs(got["cmds"][b, :n - 1] - c[:, [0, 2]])), np.max(np.abs(got["cmds_vy"][b, :n - 1] - c[:, 1])))
+        assert not got["path"][b, n:].any() and not got["cmds"][b, n - 1:].any()
+    assert worst <= 1e-11, worst
