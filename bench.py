@@ -71,6 +71,51 @@ def algorithmic_bytes_per_sweep(N, T, P, M):
     return 8 * (6 * N * T + 2 * (T + 1) + P + 5) + 16 * T + 8 * (M * P + M)
 
 
+def closed_loop_extras(prm, scenes, device_index, ticks=10):
+    """SURVEY §8 rows f1-f3 measured beside the solve: receding-horizon ticks (trajectorize -> format_to_optimize ->
+    project_people -> solve -> memory store), everything resident in HBM, plus the HIP-event time of each stage."""
+    import numpy as np
+
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode, arc_plans
+    from nav2_social_mpc_controller_amd.params import TrajectorizerParams
+    from nav2_social_mpc_controller_amd.scenes import uniform
+
+    B, T, N = scenes.B, scenes.T, scenes.N
+    tp = TrajectorizerParams(desired_linear_vel=0.6, lookahead_dist=0.4, max_angular_vel=1.0, time_step=0.05,
+                             max_time=float(prm.max_time))
+    curv = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.24
+    L = 400
+    plan, plan_len = arc_plans(scenes.pose0, curv, L=L)
+    ep = BatchEpisode(prm, scenes, curv, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]),
+                      float(np.float32(0.1)), device=device_index, plan=plan, plan_len=plan_len, traj_params=tp)
+    for _ in range(2):
+        ep.tick()
+    ep.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        ep.tick()
+    ep.synchronize()
+    tick_s = (time.perf_counter() - t0) / ticks
+    tm = {}
+    ep.tick(timing=tm)
+    S1 = tp.max_steps + 1
+    alg = {  # algorithmic bytes per scene: every input read once, every output written once
+        "trajectorize": 8 * (2 * L + 3) + 4 + 8 * S1 * (3 + 2 + 1) + 8,
+        "format": 8 * (T + 1) * (3 + 2 + 3 + 2) + 16 + 8 * ((T + 1) * (6 + 2) + 3 + 6 + 1),
+        "project": 8 * (6 * N + 6 * (T + 1)) + 8 * 6 * N * (T + 1) + 4,
+        "store": 8 * (T + 1) * 5 * 2 + 8,
+    }
+    stages = {}
+    for k in ("trajectorize", "format", "project", "store"):
+        ms = tm[k + "_ms"]
+        stages[k] = {"kernel_ms": ms, "algorithmic_GBps": B * alg[k] / (ms * 1e-3) / 1e9, "bytes_per_scene": alg[k]}
+    stages["solve"] = {"kernel_ms": tm["solve_ms"]}
+    return {"ticks_per_s": B / tick_s, "ms_per_tick": tick_s * 1e3, "ticks_timed": ticks,
+            "chain": "trajectorize(f3) -> format_to_optimize(f2) -> project_people(f1) -> solve(a1-a12) -> memory store(f2)",
+            "stages": stages, "last_tick_failures": int((ep.res["status"] == 2).sum().item()),
+            "projection_errors": int((ep.proj_error != 0).sum().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,6 +264,8 @@ def main():
             fms = fixed.last_kernel_ms()
             line["config"]["fixed_40_iterations"] = {"launch_ms": fms, "solves_per_s": B / (fms * 1e-3),
                                                      "mean_sweeps_per_solve": float(fout["evaluations"].float().mean().item())}
+        if world == 1:
+            line["config"]["closed_loop"] = closed_loop_extras(prm, scenes, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py as O
             cores = usable_cores()

@@ -140,14 +140,17 @@ class BatchEpisode:
         return {"prev_path": self.mem_path.cpu().numpy().copy(), "prev_cmds": self.mem_cmds.cpu().numpy().copy(),
                 "valid": self.mem_valid.cpu().numpy().copy()}
 
-    def tick(self, record: bool = False):
-        """One controller period for all B robots. Returns a TickRecord when `record`, else None."""
+    def tick(self, record: bool = False, timing: dict = None):
+        """One controller period for all B robots. Returns a TickRecord when `record`, else None. `timing`: a dict
+        that receives the HIP-event duration (ms) of each stage's kernel (synchronises after every stage)."""
         torch = self.torch
         s, prm, B, T, N = self.solver, self.params, self.B, self.T, self.N
         if not self.pose.is_contiguous():
             self.pose = self.pose.contiguous()
         pose_before = self.pose.cpu().numpy().copy() if record else None
         self._plan()
+        if timing is not None and self.plan is not None:
+            timing["trajectorize_ms"] = s.last_kernel_ms()
         rec = {}
         if record:
             if self.plan is not None:
@@ -166,6 +169,8 @@ class BatchEpisode:
         fo.robot_status, fo.pose0, fo.init_params = self.robot_status.data_ptr(), self.pose0.data_ptr(), self.init_params.data_ptr()
         fo.path_pts, fo.goal_yaw = self.path_pts.data_ptr(), self.goal_yaw.data_ptr()
         s.format_device(fb, fo)
+        if timing is not None:
+            timing["format_ms"] = s.last_kernel_ms()
         # 2. project_people
         pb = SmpcProjectionBatch()
         pb.B, pb.T, pb.N, pb.on_device = B, T, N, 1
@@ -175,6 +180,8 @@ class BatchEpisode:
         pb.od_width, pb.od_height, pb.od_resolution = self.od_w, self.od_h, self.od_resolution
         pb.od_origin = self.od_origin.data_ptr()
         s.project_people_device(pb, self.people_proj.data_ptr(), self.proj_error.data_ptr())
+        if timing is not None:
+            timing["project_ms"] = s.last_kernel_ms()
         # 3. solve
         sb = SmpcSceneBatch()
         sb.B, sb.T, sb.N, sb.on_device = B, T, N, 1
@@ -185,9 +192,13 @@ class BatchEpisode:
         sb.size_x, sb.size_y = self.size_x, self.size_y
         sb.costmap_origin, sb.resolution = self.costmap_origin.data_ptr(), self.resolution
         s.solve_device(sb, self.rb)
+        if timing is not None:
+            timing["solve_ms"] = s.last_kernel_ms()
         # 4. memory store (usable solves only)
         mb = self._memory_c()
         s.memory_store_device(B, T, self.res["status"].data_ptr(), self.res["path"].data_ptr(), self.res["cmds"].data_ptr(), mb)
+        if timing is not None:
+            timing["store_ms"] = s.last_kernel_ms()
         if record:
             rec.update(robot_status=self.robot_status.cpu().numpy().copy(), pose0=self.pose0.cpu().numpy().copy(),
                        init_params=self.init_params.cpu().numpy().copy(), path_pts=self.path_pts.cpu().numpy().copy(),
@@ -217,3 +228,15 @@ def far_obstacle_grid(cells: int = 120, resolution: float = 0.1, origin=(-6.0, -
     """An ObstacleDistance grid whose every cell points at one far corner obstacle (valid, but inert for the crowd)."""
     idx = np.zeros((cells, cells), np.uint32)  # all cells -> cell 0 (the grid corner)
     return idx, np.asarray(origin, np.float64), float(np.float32(resolution))
+
+
+def arc_plans(pose0: np.ndarray, curvature: np.ndarray, L: int = 400, ds: float = 0.05):
+    """Synthetic global plans: constant-curvature arcs of L poses (spacing ds) from each robot's start pose.
+    Returns (plan [B,L,2], plan_len [B])."""
+    B = pose0.shape[0]
+    plan = np.zeros((B, L, 2))
+    x, y, th = pose0[:, 0].copy(), pose0[:, 1].copy(), pose0[:, 2].copy()
+    for i in range(L):
+        plan[:, i, 0], plan[:, i, 1] = x, y
+        x, y, th = x + ds * np.cos(th), y + ds * np.sin(th), th + curvature * ds
+    return plan, np.full(B, L, np.int32)

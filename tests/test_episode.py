@@ -64,21 +64,10 @@ def test_episode_ticks_match_cpu_chain(oracle):
     assert np.max(np.abs(ep.pose.cpu().numpy()[:, :2] - sc.pose0[:, :2])) > 0.02
 
 
-def arc_plans(pose0, w_ref, L=400, ds=0.05):
-    """Global plans: constant-curvature arcs of L poses from each robot's start pose."""
-    B = pose0.shape[0]
-    plan = np.zeros((B, L, 2))
-    x, y, th = pose0[:, 0].copy(), pose0[:, 1].copy(), pose0[:, 2].copy()
-    for i in range(L):
-        plan[:, i, 0], plan[:, i, 1] = x, y
-        x, y, th = x + ds * np.cos(th), y + ds * np.sin(th), th + 0.4 * w_ref * ds  # radius >= 4.2 m: the 20 m arc never closes
-    return plan, np.full(B, L, np.int32)
-
-
 @pytest.mark.gpu
 def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
     """Plan mode: trajectorize (f3) -> format (f2, cut to T + 1 of the max_steps + 1 poses) -> project (f1) -> solve."""
-    from nav2_social_mpc_controller_amd.episode import BatchEpisode
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode, arc_plans
     from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
     from nav2_social_mpc_controller_amd.scenes import SceneBatch, make_scenes, uniform
     from oracle import pyref_format, pyref_trajectorize
@@ -91,7 +80,7 @@ def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
     assert tp.max_steps + 1 > T + 1 == prm.rollout_steps + 1       # the cut of format_to_optimize applies
     CH, bl, nb, P, M, _ = prm.dims(T, True)
     w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
-    plan, plan_len = arc_plans(sc.pose0, w_ref)
+    plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)  # radius >= 4.2 m: the 20 m arc never closes on itself
     ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)),
                       plan=plan, plan_len=plan_len, traj_params=tp)
     for tick in range(3):

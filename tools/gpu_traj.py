@@ -1,0 +1,30 @@
+"""Development probe: trajectorize kernel timing."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from nav2_social_mpc_controller_amd.episode import arc_plans
+from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
+from nav2_social_mpc_controller_amd.solver import BatchSolver
+from nav2_social_mpc_controller_amd._abi import SmpcTrajectorizeOut
+import torch
+B = 8192
+rng = np.random.default_rng(0)
+pose = np.stack([rng.uniform(-5, 5, B), rng.uniform(-5, 5, B), rng.uniform(-3, 3, B)], 1)
+plan, plan_len = arc_plans(pose, rng.uniform(-0.24, 0.24, B), L=400)
+tp = TrajectorizerParams(desired_linear_vel=0.6, max_time=1.5)
+s = BatchSolver(OptimizerParams.readme())
+dev = "cuda:0"
+tb = s.trajectorize_c(tp, B, 400, 1)
+t = {"plan": torch.from_numpy(plan).to(dev), "len": torch.from_numpy(plan_len).to(dev), "pose": torch.from_numpy(pose).to(dev)}
+S1 = tp.max_steps + 1
+f64 = dict(dtype=torch.float64, device=dev)
+o = {"path": torch.zeros((B, S1, 3), **f64), "cmds": torch.zeros((B, S1, 2), **f64), "vy": torch.zeros((B, S1), **f64),
+     "n": torch.zeros(B, dtype=torch.int32, device=dev), "e": torch.zeros(B, dtype=torch.int32, device=dev)}
+to = SmpcTrajectorizeOut()
+tb.plan, tb.plan_len, tb.robot_pose = t["plan"].data_ptr(), t["len"].data_ptr(), t["pose"].data_ptr()
+to.path, to.cmds, to.cmds_vy, to.n_poses, to.error = o["path"].data_ptr(), o["cmds"].data_ptr(), o["vy"].data_ptr(), o["n"].data_ptr(), o["e"].data_ptr()
+ms = []
+for _ in range(6):
+    s.trajectorize_device(tb, to)
+    ms.append(s.last_kernel_ms())
+print("trajectorize B=8192 L=400: ms", [round(m, 3) for m in ms], "n_poses mean", o["n"].double().mean().item(), "errors", int((o["e"] != 0).sum()))
