@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--people", type=int, default=8)
     ap.add_argument("--fixed-iterations", type=int, default=0, help="1: run exactly 40 LM iterations per scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra measurements in `config` (PCIe-inclusive, fixed-40, closed loop): profiling runs")
     ap.add_argument("--streams", type=int, default=4,
                     help="consecutive steps are issued round-robin on this many HIP streams (one solver handle each)")
     args = ap.parse_args()
@@ -251,7 +253,7 @@ def main():
                          "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
                          "k1_sweep_kernel": {"launch_ms": k1_ms, "achieved": k1_achieved, "frac": k1_achieved / HBM_PEAK_GBS}},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # extras of SURVEY §8(d): (ii) end-to-end including PCIe staging, (iii) fixed-40-iteration mode
             t1 = time.perf_counter()
             solver.solve(scenes)                      # host pointers: H2D of every input, solve, D2H of every output
@@ -264,7 +266,7 @@ def main():
             fms = fixed.last_kernel_ms()
             line["config"]["fixed_40_iterations"] = {"launch_ms": fms, "solves_per_s": B / (fms * 1e-3),
                                                      "mean_sweeps_per_solve": float(fout["evaluations"].float().mean().item())}
-        if world == 1:
+        if world == 1 and not args.no_extras:
             line["config"]["closed_loop"] = closed_loop_extras(prm, scenes, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle_py as O

@@ -2,8 +2,8 @@
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from nav2_social_mpc_controller_amd.episode import BatchEpisode
-from nav2_social_mpc_controller_amd.params import OptimizerParams
+from nav2_social_mpc_controller_amd.episode import BatchEpisode, arc_plans
+from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
 from nav2_social_mpc_controller_amd.scenes import make_scenes, uniform
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
@@ -12,7 +12,11 @@ ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 prm = OptimizerParams.readme()
 sc = make_scenes(prm, B, N)
 w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
-ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1)
+kw = {}
+if len(sys.argv) > 4 and sys.argv[4] == "plan":  # global plans trajectorized on the device every tick (row f3)
+    plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)
+    kw = dict(plan=plan, plan_len=plan_len, traj_params=TrajectorizerParams(desired_linear_vel=0.6, max_time=prm.max_time))
+ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1, **kw)
 for _ in range(2):
     ep.tick()
 ep.synchronize()
