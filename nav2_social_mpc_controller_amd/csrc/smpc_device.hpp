@@ -112,6 +112,13 @@ __host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
   return use_mfma(P, W) ? (kWave / W) * tile_slot_stride(W) + 256 : 0;
 }
 
+// Stand-alone K1: the MFMA row / result tiles are only used after the agent loop, when the staged people block of the
+// wave is dead — they overlay slot 0's people block when it is large enough (keeps a W = 32 wave at ~19 KB of LDS, 8
+// waves per CU instead of 6).
+__host__ __device__ constexpr bool k1_tiles_overlay_people(int T, int N, int P, int W) {
+  return wave_extra_doubles(P, W) > 0 && 4 * T * (N > 0 ? N : 1) >= wave_extra_doubles(P, W);
+}
+
 // The workgroup is ONE wavefront: LDS operations of a wave execute in program order, so cross-lane hand-offs through
 // LDS only need the compiler not to reorder them — no s_barrier and, importantly, no s_waitcnt vmcnt(0) that a
 // __syncthreads() would add (it would drain unrelated global loads / stores at every hand-off).

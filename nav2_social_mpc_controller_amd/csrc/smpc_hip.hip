@@ -143,7 +143,8 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   const int S = smpc::kWave / W;
   KernelFn fn = pick(k.nb, W, eval);
   const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, !eval);
-  const size_t shmem = ((size_t)S * L.total + smpc::wave_extra_doubles(k.P, W)) * sizeof(double);
+  const bool overlay = eval && smpc::k1_tiles_overlay_people(k.T, k.N, k.P, W);
+  const size_t shmem = ((size_t)S * L.total + (overlay ? 0 : smpc::wave_extra_doubles(k.P, W))) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
   if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (k.B == 0) return SMPC_OK;

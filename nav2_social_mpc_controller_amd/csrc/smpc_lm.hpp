@@ -846,7 +846,7 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
   c.sl = lane - slot * W;
   c.L = make_layout(k.T, k.N, P, false);
   c.lds = lds_all + (size_t)slot * c.L.total;
-  c.wave_lds = lds_all + (size_t)S * c.L.total;
+  c.wave_lds = k1_tiles_overlay_people(k.T, k.N, P, W) ? lds_all + c.L.ag : lds_all + (size_t)S * c.L.total;
   c.slot = slot;
   c.ag = c.lds + c.L.ag;  // staged people block in LDS
 #ifdef SMPC_STAMPS
