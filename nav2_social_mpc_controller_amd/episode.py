@@ -109,6 +109,7 @@ class BatchEpisode:
         self.proj_error = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.rb, self.res = self.solver.alloc_results(B, T, self.dev)
         self.ticks = 0
+        self.parked = None  # plan mode: scenes parked in the last tick (bool tensor)
 
     # -- trajectorizer (row f3) on the global plans, or the arc stand-in: v = 0.6, w = w_ref from the current pose --
     def _plan(self):
@@ -194,6 +195,12 @@ class BatchEpisode:
         s.solve_device(sb, self.rb)
         if timing is not None:
             timing["solve_ms"] = s.last_kernel_ms()
+        # scenes whose trajectorized path is shorter than the horizon (the robot is about to reach the end of its plan)
+        # would need a smaller T than the batch has: they are parked — treated like an unusable solve from here on
+        if self.plan is not None:
+            parked = self.traj_n < (T + 1)
+            self.res["status"].masked_fill_(parked, 2)
+            self.parked = parked
         # 4. memory store (usable solves only)
         mb = self._memory_c()
         s.memory_store_device(B, T, self.res["status"].data_ptr(), self.res["path"].data_ptr(), self.res["cmds"].data_ptr(), mb)
