@@ -207,6 +207,21 @@ typedef struct smpc_memory_batch {
   int32_t* valid;     /* [B] 0 while previous_path.poses.size() == 0 (src/optimizer.cpp:177) */
 } smpc_memory_batch;
 
+/* Optimizer::people_to_status (src/optimizer.cpp:454-482) for B scenes: people_msgs::Person position / velocity ->
+ * AgentStatus rows (x, y, yaw = atan2(vy, vx), t = 0, lv = |v|, av = velocity.z), padded with invalid agents (t = -1) or
+ * truncated to N agents (the reference hard-codes N = 3). has_people = people.people.size() != 0 (:263). */
+typedef struct smpc_people_batch {
+  int32_t B;
+  int32_t Np;        /* row stride of `people`: the most persons any scene has (>= 1) */
+  int32_t N;         /* agents per scene in the output */
+  int32_t on_device; /* 0: host pointers, 1: device pointers (outputs follow) */
+  const double* people;  /* [B][Np][5] position.x, position.y, velocity.x, velocity.y, velocity.z */
+  const int32_t* count;  /* [B] persons of each scene */
+} smpc_people_batch;
+
+int smpc_people_to_status_batch(smpc_handle* h, const smpc_people_batch* in, double* init_people /* [B][N][6] */,
+                                uint8_t* has_people /* [B]; may be NULL */);
+
 /* Optimizer::format_to_optimize (src/optimizer.cpp:484-551) for B scenes whose incoming path has already been cut to
  * T + 1 poses (the cut to round(max_time / time_step) - 1 poses, :492-497, is a host-side length decision), followed by
  * what Optimizer::optimize derives from its result before building the problem (:197-261). Scenes with an empty memory

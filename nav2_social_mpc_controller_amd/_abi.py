@@ -96,6 +96,17 @@ class SmpcProjectionBatch(C.Structure):
     ]
 
 
+class SmpcPeopleBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("Np", C.c_int32),
+        ("N", C.c_int32),
+        ("on_device", C.c_int32),
+        ("people", C.c_void_p),
+        ("count", C.c_void_p),
+    ]
+
+
 class SmpcMemoryBatch(C.Structure):
     _fields_ = [
         ("prev_path", C.c_void_p),
@@ -190,6 +201,7 @@ EXPORTED_SYMBOLS = [
     "smpc_solve_batch",
     "smpc_eval_batch",
     "smpc_project_people_batch",
+    "smpc_people_to_status_batch",
     "smpc_format_to_optimize_batch",
     "smpc_memory_store_batch",
     "smpc_trajectorize_path_batch",

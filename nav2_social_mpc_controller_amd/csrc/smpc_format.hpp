@@ -86,6 +86,31 @@ __global__ __launch_bounds__(256) void smpc_format_mark_kernel(int B, int32_t* v
   if (s < B) valid[s] = 1;
 }
 
+struct PeopleParams {
+  int B, Np, N;
+  const double* people;   // [B][Np][5]
+  const int32_t* count;   // [B]
+  double* init_people;    // [B][N][6]
+  uint8_t* has_people;    // [B] or null
+};
+
+// Optimizer::people_to_status (src/optimizer.cpp:454-482): one lane per (scene, output agent).
+__global__ __launch_bounds__(256) void smpc_people_to_status_kernel(const PeopleParams p) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)p.B * p.N) return;
+  const int s = (int)(gid / p.N), a = (int)(gid - (long long)s * p.N);
+  const int cnt = p.count[s];
+  double* o = p.init_people + (size_t)gid * 6;
+  if (a < cnt && a < p.Np) {
+    const double* q = p.people + ((size_t)s * p.Np + a) * 5;
+    const double vx = q[2], vy = q[3];
+    o[0] = q[0]; o[1] = q[1]; o[2] = atan2(vy, vx); o[3] = 0.0; o[4] = sqrt(vx * vx + vy * vy); o[5] = q[4];
+  } else {  // "we fill with invalid agent: time=-1" (:470-476)
+    o[0] = 0.0; o[1] = 0.0; o[2] = 0.0; o[3] = -1.0; o[4] = 0.0; o[5] = 0.0;
+  }
+  if (a == 0 && p.has_people) p.has_people[s] = cnt != 0 ? 1 : 0;
+}
+
 struct StoreParams {
   int B, T;
   const int32_t* status;

@@ -398,6 +398,40 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
   return SMPC_OK;
 }
 
+int smpc_people_to_status_batch(smpc_handle* h, const smpc_people_batch* in, double* init_people, uint8_t* has_people) {
+  if (!h || !in || !init_people) { set_error("null handle / input / output"); return SMPC_ERR_INVALID_ARG; }
+  if (in->B < 0 || in->Np < 1 || in->N < 1) { set_error("bad B / Np / N"); return SMPC_ERR_INVALID_ARG; }
+  if (!in->people || !in->count) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t B = in->B, Np = in->Np, N = in->N;
+  smpc::PeopleParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = in->B; p.Np = in->Np; p.N = in->N;
+  Staging st;
+  if (in->on_device) {
+    p.people = in->people; p.count = in->count; p.init_people = init_people; p.has_people = has_people;
+  } else {
+    SMPC_TRY(st.up(in->people, B * Np * 5, &p.people, h->stream));
+    SMPC_TRY(st.up(in->count, B, &p.count, h->stream));
+    SMPC_TRY(st.out(init_people, B * N * 6, &p.init_people));
+    SMPC_TRY(st.out(has_people, B, &p.has_people));
+  }
+  if (B > 0) {
+    const long long n = (long long)B * (long long)N;
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_people_to_status_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!in->on_device) {
+    SMPC_TRY(down(init_people, p.init_people, B * N * 6, h->stream));
+    SMPC_TRY(down(has_people, p.has_people, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
 int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, smpc_format_out* out) {
   if (!h || !in || !out) { set_error("null handle / input / output"); return SMPC_ERR_INVALID_ARG; }
   if (in->B < 0 || in->T < 1) { set_error("bad B/T"); return SMPC_ERR_INVALID_ARG; }

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import (SmpcEvalOut, SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcParams, SmpcProjectionBatch,
+from ._abi import (SmpcEvalOut, SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcParams, SmpcPeopleBatch, SmpcProjectionBatch,
                    SmpcResultBatch, SmpcSceneBatch, SmpcTrajectorizeBatch, SmpcTrajectorizeOut)
 from .params import OptimizerParams, TrajectorizerParams
 from .scenes import SceneBatch
@@ -60,6 +60,8 @@ def load_library():
     lib.smpc_eval_batch.restype = C.c_int
     lib.smpc_project_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcProjectionBatch), C.c_void_p, C.c_void_p]
     lib.smpc_project_people_batch.restype = C.c_int
+    lib.smpc_people_to_status_batch.argtypes = [C.c_void_p, C.POINTER(SmpcPeopleBatch), C.c_void_p, C.c_void_p]
+    lib.smpc_people_to_status_batch.restype = C.c_int
     lib.smpc_format_to_optimize_batch.argtypes = [C.c_void_p, C.POINTER(SmpcFormatBatch), C.POINTER(SmpcFormatOut)]
     lib.smpc_format_to_optimize_batch.restype = C.c_int
     lib.smpc_memory_store_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -198,6 +200,20 @@ class BatchSolver:
     def trajectorize_device(self, tb: SmpcTrajectorizeBatch, to: SmpcTrajectorizeOut):
         assert tb.on_device == 1
         _check(self.lib, self.lib.smpc_trajectorize_path_batch(self._h, C.byref(tb), C.byref(to)), "smpc_trajectorize_path_batch")
+
+    def people_to_status(self, people: np.ndarray, count: np.ndarray, N: int = 3):
+        """Optimizer::people_to_status for B scenes: people [B,Np,5] (px, py, vx, vy, vz), count [B] ->
+        (init_people [B,N,6], has_people [B] uint8)."""
+        people = np.ascontiguousarray(people, np.float64)
+        count = np.ascontiguousarray(count, np.int32)
+        B, Np, _ = people.shape
+        pb = SmpcPeopleBatch()
+        pb.B, pb.Np, pb.N, pb.on_device = B, Np, N, 0
+        pb.people, pb.count = people.ctypes.data, count.ctypes.data
+        out, has = np.zeros((B, N, 6)), np.zeros(B, np.uint8)
+        _check(self.lib, self.lib.smpc_people_to_status_batch(self._h, C.byref(pb), out.ctypes.data, has.ctypes.data),
+               "smpc_people_to_status_batch")
+        return out, has
 
     # -- warm start / input formatting (SURVEY §8 row f2): format_to_optimize + TrajectoryMemory for B scenes -----
     def format_to_optimize(self, path: np.ndarray, cmds: np.ndarray, speed: np.ndarray, memory: dict,

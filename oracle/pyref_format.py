@@ -65,3 +65,15 @@ def memory_store(status, path, cmds, memory):
             memory["prev_path"][s] = path[s]
             memory["prev_cmds"][s] = cmds[s]
             memory["valid"][s] = 1
+
+
+def people_to_status(people, count, N=3):
+    """Optimizer::people_to_status (reference src/optimizer.cpp:454-482): people [B][Np][5] (px, py, vx, vy, vz)."""
+    B = people.shape[0]
+    out = np.zeros((B, N, 6))
+    out[:, :, 3] = -1.0
+    for s in range(B):
+        for a in range(min(int(count[s]), N, people.shape[1])):
+            px, py, vx, vy, vz = people[s, a]
+            out[s, a] = (px, py, math.atan2(vy, vx), 0.0, math.sqrt(vx * vx + vy * vy), vz)
+    return out, (np.asarray(count) != 0).astype(np.uint8)

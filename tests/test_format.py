@@ -141,3 +141,28 @@ def test_gpu_memory_store_matches_pyref():
     for k in mem:
         assert np.array_equal(mem[k], mem_ref[k]), k
     assert (status == 2).any() and (mem["valid"] == (status != 2)).all()
+
+
+def test_pyref_people_to_status_pads_and_truncates():
+    from oracle import pyref_format
+    people = np.random.default_rng(10).normal(size=(4, 5, 5))
+    out, has = pyref_format.people_to_status(people, np.array([0, 2, 3, 5]), 3)
+    assert has.tolist() == [0, 1, 1, 1]
+    assert (out[0, :, 3] == -1).all() and out[1, :2, 3].tolist() == [0, 0] and out[1, 2, 3] == -1 and (out[3, :, 3] == 0).all()
+    assert np.allclose(out[3, 2, 4], np.hypot(people[3, 2, 2], people[3, 2, 3]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [3, 8])
+def test_gpu_people_to_status_matches_pyref(N):
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    from oracle import pyref_format
+    rng = np.random.default_rng(11)
+    B, Np = 300, 10
+    people = rng.normal(size=(B, Np, 5))
+    people[::7, :, 2:4] = 0.0  # standing people: yaw = atan2(0, 0) = 0
+    count = rng.integers(0, Np + 1, size=B).astype(np.int32)
+    got, has = BatchSolver(OptimizerParams.readme()).people_to_status(people, count, N)
+    exp, ehas = pyref_format.people_to_status(people, count, N)
+    assert np.array_equal(has, ehas) and np.max(np.abs(got - exp)) <= 1e-14
