@@ -125,10 +125,15 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
       fx += e * (z > 0 ? mx / mn : mx);
       fy += e * (z > 0 ? my / mn : my);
     }
-    for (int j = 0; j < n_act; ++j) {  // computeSocialForce(index, agents) :237-281
+    // computeSocialForce(index, agents) :237-281. The force on i from j is the exact negative of the force on j from i
+    // (diff, velocity difference and with them the interaction vector flip sign; theta, B and both exponentials are
+    // unchanged), so every unordered pair is evaluated once: in round k lane i takes partner (i + k) mod n and hands the
+    // negated force to it by shuffle; for even n the last round (k = n/2) pairs lanes mutually and needs no hand-over.
+    // The sum over partners runs in round order instead of index order (differences at round-off level).
+    for (int kk = 1; 2 * kk <= n_act; ++kk) {
+      const int j = (g + kk) % n_act;
       const double qx = __shfl(px, base + j, 64), qy = __shfl(py, base + j, 64);
       const double wx = __shfl(vx, base + j, 64), wy = __shfl(vy, base + j, 64);
-      if (j == g || g >= n_act) continue;
       const double dfx = qx - px, dfy = qy - py;
       const double z = dfx * dfx + dfy * dfy;
       const double nd = sqrt(z);
@@ -144,8 +149,15 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
       const double fv = -exp(-nd / Bq - (kNp * Bq * theta) * (kNp * Bq * theta));
       const double sgn = (theta == 0) ? 0.0 : ((theta > 0) ? 1.0 : -1.0);  // sfm.hpp:265-270
       const double fa = -sgn * exp(-nd / Bq - (kN * Bq * theta) * (kN * Bq * theta));
-      fx += kFs * (fv * ix + fa * (-iy));
-      fy += kFs * (fv * iy + fa * ix);
+      const double sfx = kFs * (fv * ix + fa * (-iy));
+      const double sfy = kFs * (fv * iy + fa * ix);
+      const bool act = g < n_act;
+      if (act) { fx += sfx; fy += sfy; }
+      if (2 * kk != n_act) {
+        const int src = (g - kk + n_act) % n_act;
+        const double rx = __shfl(sfx, base + src, 64), ry = __shfl(sfy, base + src, 64);
+        if (act) { fx -= rx; fy -= ry; }
+      }
     }
     // ---- updatePosition (sfm.hpp:525-551)
     vx += fx * dt; vy += fy * dt;

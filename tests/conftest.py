@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # one HIP runtime per process: PyTorch-ROCm brings its own libamdhip64 and must be loaded before any in-tree
+    import torch  # noqa: F401  library (libsmpc_hip.so, libsmpc_host.so) pulls in /opt/rocm's copy
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
