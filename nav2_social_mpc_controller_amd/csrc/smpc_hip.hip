@@ -64,6 +64,9 @@ struct smpc_handle {
   int* queue;  // device-side scene queue head
   double* ws_ag;  // staged-people workspace of the persistent solve kernel
   size_t ws_ag_bytes;
+  char* stage;        // grow-only arena for host-pointer calls (the plugin's B = 1 use): no hipMalloc per call
+  size_t stage_cap;
+  size_t stage_want;  // high-water mark of the calls so far
 };
 
 namespace {
@@ -111,16 +114,43 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
   k->e_M = d.M;
 }
 
-// Host-pointer batches are staged through device memory by this helper.
+#define SMPC_TRY_(expr) do { int _rc = (expr); if (_rc != SMPC_OK) return _rc; } while (0)
+
+// Host-pointer batches are staged through device memory by this helper: sub-allocations of the handle's arena, which
+// grows to the high-water mark at the start of the next call (every host-pointer call ends with a stream synchronise,
+// so nothing is in flight then); what does not fit meanwhile comes from hipMalloc and is freed when the call returns.
 struct Staging {
-  std::vector<void*> allocs;
-  ~Staging() { for (void* p : allocs) (void)hipFree(p); }
+  smpc_handle* h;
+  size_t off = 0, need = 0;
+  std::vector<void*> overflow;
+  explicit Staging(smpc_handle* handle) : h(handle) {
+    if (h && h->stage_want > h->stage_cap) {
+      if (h->stage) (void)hipFree(h->stage);
+      h->stage = nullptr; h->stage_cap = 0;
+      const size_t cap = h->stage_want + h->stage_want / 4;
+      void* p = nullptr;
+      if (hipMalloc(&p, cap) == hipSuccess) { h->stage = static_cast<char*>(p); h->stage_cap = cap; }
+    }
+  }
+  ~Staging() {
+    for (void* p : overflow) (void)hipFree(p);
+    if (h && need > h->stage_want) h->stage_want = need;
+  }
+  int take(size_t bytes, void** out) {
+    const size_t sz = (bytes + 255) & ~(size_t)255;
+    need += sz;
+    if (h && h->stage && off + sz <= h->stage_cap) { *out = h->stage + off; off += sz; return SMPC_OK; }
+    void* p = nullptr;
+    SMPC_HIP_CHECK(hipMalloc(&p, sz));
+    overflow.push_back(p);
+    *out = p;
+    return SMPC_OK;
+  }
   template <typename T> int up(const T* host, size_t n, const T** dev, hipStream_t st) {
     *dev = nullptr;
     if (!host || n == 0) return SMPC_OK;
     void* p = nullptr;
-    SMPC_HIP_CHECK(hipMalloc(&p, n * sizeof(T)));
-    allocs.push_back(p);
+    SMPC_TRY_(take(n * sizeof(T), &p));
     SMPC_HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, st));
     *dev = static_cast<const T*>(p);
     return SMPC_OK;
@@ -129,8 +159,7 @@ struct Staging {
     *dev = nullptr;
     if (!host || n == 0) return SMPC_OK;
     void* p = nullptr;
-    SMPC_HIP_CHECK(hipMalloc(&p, n * sizeof(T)));
-    allocs.push_back(p);
+    SMPC_TRY_(take(n * sizeof(T), &p));
     *dev = static_cast<T*>(p);
     return SMPC_OK;
   }
@@ -280,6 +309,9 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
   h->queue = nullptr;
   h->ws_ag = nullptr;
   h->ws_ag_bytes = 0;
+  h->stage = nullptr;
+  h->stage_cap = 0;
+  h->stage_want = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); delete h; return nullptr; }
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -294,6 +326,7 @@ void smpc_destroy(smpc_handle* h) {
   (void)hipEventDestroy(h->ev1);
   if (h->queue) (void)hipFree(h->queue);
   if (h->ws_ag) (void)hipFree(h->ws_ag);
+  if (h->stage) (void)hipFree(h->stage);
   delete h;
 }
 
@@ -318,7 +351,7 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   SMPC_HIP_CHECK(hipSetDevice(h->device));
   smpc::KParams k;
   fill_kparams(h, sb, d, &k);
-  Staging st;
+  Staging st(h);
   SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
   const size_t B = sb->B, T = sb->T;
   if (sb->on_device) {
@@ -369,7 +402,7 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
   p.od_shared = in->od_shared; p.od_width = in->od_width; p.od_height = in->od_height;
   const size_t B = in->B, T = in->T, N = in->N;
   const size_t ngrid = in->od_shared ? 1 : B;
-  Staging st;
+  Staging st(h);
   if (in->on_device) {
     p.init_people = in->init_people; p.robot_path = in->robot_path; p.od_indexes = in->od_indexes; p.od_origin = in->od_origin;
     p.people_proj = people_proj; p.error = error;
@@ -407,7 +440,7 @@ int smpc_people_to_status_batch(smpc_handle* h, const smpc_people_batch* in, dou
   smpc::PeopleParams p;
   std::memset(&p, 0, sizeof(p));
   p.B = in->B; p.Np = in->Np; p.N = in->N;
-  Staging st;
+  Staging st(h);
   if (in->on_device) {
     p.people = in->people; p.count = in->count; p.init_people = init_people; p.has_people = has_people;
   } else {
@@ -450,7 +483,7 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
   if (rows < Tp) { set_error("path_rows < T + 1"); return SMPC_ERR_INVALID_ARG; }
   p.B = in->B; p.T = in->T; p.nb = d.nb; p.P = d.P; p.rows = (int)rows;
   p.time_step = in->time_step; p.current_path_w = in->current_path_w; p.current_cmds_w = in->current_cmds_w;
-  Staging st;
+  Staging st(h);
   if (in->on_device) {
     p.path = in->path; p.cmds = in->cmds; p.speed = in->speed;
     p.prev_path = in->memory.prev_path; p.prev_cmds = in->memory.prev_cmds; p.valid = in->memory.valid;
@@ -505,7 +538,7 @@ int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_de
   smpc::StoreParams p;
   std::memset(&p, 0, sizeof(p));
   p.B = B_; p.T = T;
-  Staging st;
+  Staging st(h);
   if (on_device) {
     p.status = status; p.path = path; p.cmds = cmds;
     p.prev_path = memory->prev_path; p.prev_cmds = memory->prev_cmds; p.valid = memory->valid;
@@ -547,7 +580,7 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
   p.B = in->B; p.L = in->L; p.max_steps = in->max_steps; p.omnidirectional = in->omnidirectional;
   p.desired_linear_vel = in->desired_linear_vel; p.lookahead_dist = in->lookahead_dist;
   p.max_angular_vel = in->max_angular_vel; p.time_step = in->time_step;
-  Staging st;
+  Staging st(h);
   if (in->on_device) {
     p.plan = in->plan; p.plan_len = in->plan_len; p.robot_pose = in->robot_pose;
     p.path = out->path; p.cmds = out->cmds; p.cmds_vy = out->cmds_vy; p.n_poses = out->n_poses; p.error = out->error;
@@ -587,7 +620,7 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* pa
   SMPC_HIP_CHECK(hipSetDevice(h->device));
   smpc::KParams k;
   fill_kparams(h, sb, d, &k);
-  Staging st;
+  Staging st(h);
   SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
   const size_t B = sb->B;
   if (sb->on_device) {
