@@ -135,6 +135,9 @@ template <int W> __device__ inline double slot_sum(double v) {
 }
 
 __device__ inline double wrap_to_pi(double a) {  // critics/social_work_cost_function.hpp:39-46
+  // only ever called on a difference of two atan2 results (|a| <= 2 pi, or NaN): at most one trip per loop; the guard
+  // keeps the wave finite should that ever change
+  if (!(fabs(a) <= 8.0 * M_PI)) a = fmod(a, 2.0 * M_PI);
   while (a > M_PI) a -= 2.0 * M_PI;
   while (a <= -M_PI) a += 2.0 * M_PI;
   return a;

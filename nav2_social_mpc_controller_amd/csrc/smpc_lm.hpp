@@ -475,7 +475,9 @@ __device__ inline bool cholesky_solve(const double (&Hl)[P * (P + 1) / 2], const
   return ok;
 }
 
-__device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+// std::min(std::max(v, lo), hi) of parameter_block.h Plus(): a NaN stays a NaN (fmin / fmax alone would drop it and a
+// NaN warm start would be solved from the lower bound instead of failing its initial evaluation like Ceres)
+__device__ inline double clampd(double v, double lo, double hi) { return (v != v) ? v : fmin(fmax(v, lo), hi); }
 
 // tf2 Quaternion::setRPY(0,0,yaw) followed by tf2::getYaw (x = y = 0): src/optimizer.cpp:434-439 round trips.
 __device__ inline double yaw_roundtrip(double yaw) {

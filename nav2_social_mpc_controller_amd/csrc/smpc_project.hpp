@@ -24,7 +24,12 @@ struct ProjParams {
   int32_t* error;
 };
 
+// The reference normalises angles by repeated +-2 pi (sfm angle.hpp); every argument on this path is a difference of
+// atan2 results except `yaw - init_yaw` at step 0, where init_yaw is caller data. A wave must terminate whatever the
+// input: beyond 8 pi the value is pre-reduced with fmod (non-finite input comes back as NaN), within it the loop is the
+// reference's own arithmetic.
 __device__ inline double proj_wrap(double a) {
+  if (!(fabs(a) <= 8.0 * M_PI)) a = fmod(a, 2 * M_PI);
   while (a <= -M_PI) a += 2 * M_PI;
   while (a > M_PI) a -= 2 * M_PI;
   return a;

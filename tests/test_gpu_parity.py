@@ -292,3 +292,25 @@ def test_randomised_parameter_sets(Solver, oracle, case):
     assert np.max(cmd_err(rg["cmds"][firm], rz["cmds"][firm])) <= CMD_TOL
     assert np.array_equal(rg["iterations"][firm], rz["iterations"][firm])
     assert np.array_equal(rg["status"][firm], rz["status"][firm])
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_inputs_terminate_and_fail_cleanly(Solver):
+    """Every wave must reach its exit whatever the input (a hung wave can take the GPU down): scenes with NaN / inf in
+    their people, path or start pose end as FAILURE (non-finite initial evaluation, like Ceres), neighbours are not
+    affected."""
+    prm = README
+    sc = make_scenes(prm, 64, 8, seed=601, map_cells=80)
+    clean = Solver(prm).solve(sc)
+    bad = sc.select(np.arange(64))
+    bad.people[3, :, 0, 2] = np.nan           # one agent's x
+    bad.people[7, :, 2, :] = np.inf           # every yaw of a scene
+    bad.pose0[11, 2] = np.nan                 # start heading
+    bad.path_pts[13, 5, 0] = np.inf           # one path point
+    bad.init_params[17, 1] = np.nan           # warm-start command
+    out = Solver(prm).solve(bad)
+    hit = np.array([3, 7, 11, 13, 17])
+    assert np.all(out["status"][hit] == 2), out["status"][hit]
+    rest = np.setdiff1d(np.arange(64), hit)
+    assert np.array_equal(out["status"][rest], clean["status"][rest])
+    assert np.max(np.abs(out["cmds"][rest] - clean["cmds"][rest])) == 0.0
