@@ -87,7 +87,8 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
     L = 400
     plan, plan_len = arc_plans(scenes.pose0, curv, L=L)
     ep = BatchEpisode(prm, scenes, curv, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]),
-                      float(np.float32(0.1)), device=device_index, plan=plan, plan_len=plan_len, traj_params=tp)
+                      float(np.float32(0.1)), device=device_index, plan=plan, plan_len=plan_len, traj_params=tp,
+                      fov_angle=np.pi)  # pi: everybody on the costmap is seen, the 8-agent workload of the headline config
     for _ in range(2):
         ep.tick()
     ep.synchronize()
@@ -105,13 +106,15 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
         "project": 8 * (6 * N + 6 * (T + 1)) + 8 * 6 * N * (T + 1) + 4,
         "store": 8 * (T + 1) * 5 * 2 + 8,
     }
+    alg["people"] = 8 * 5 * N + 4 + 8 * 3 + 8 * 6 * N + 1
     stages = {}
-    for k in ("trajectorize", "format", "project", "store"):
+    for k in ("trajectorize", "people", "format", "project", "store"):
         ms = tm[k + "_ms"]
         stages[k] = {"kernel_ms": ms, "algorithmic_GBps": B * alg[k] / (ms * 1e-3) / 1e9, "bytes_per_scene": alg[k]}
     stages["solve"] = {"kernel_ms": tm["solve_ms"]}
     return {"ticks_per_s": B / tick_s, "ms_per_tick": tick_s * 1e3, "ticks_timed": ticks,
-            "chain": "trajectorize(f3) -> format_to_optimize(f2) -> project_people(f1) -> solve(a1-a12) -> memory store(f2)",
+            "chain": "trajectorize(f3) -> fov filter + people_to_status(f4, f2) -> format_to_optimize(f2) -> project_people(f1) "
+                     "-> solve(a1-a12) -> memory store(f2)",
             "stages": stages, "last_tick_failures": int((ep.res["status"] == 2).sum().item()),
             "projection_errors": int((ep.proj_error != 0).sum().item())}
 

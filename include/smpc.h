@@ -209,7 +209,10 @@ typedef struct smpc_memory_batch {
 
 /* Optimizer::people_to_status (src/optimizer.cpp:454-482) for B scenes: people_msgs::Person position / velocity ->
  * AgentStatus rows (x, y, yaw = atan2(vy, vx), t = 0, lv = |v|, av = velocity.z), padded with invalid agents (t = -1) or
- * truncated to N agents (the reference hard-codes N = 3). has_people = people.people.size() != 0 (:263). */
+ * truncated to N agents (the reference hard-codes N = 3). has_people = people.people.size() != 0 (:263).
+ * Optionally preceded by the field-of-view filter of SocialMPCController::computeVelocityCommands
+ * (src/social_mpc_controller.cpp:196-214): a person is kept when Costmap2D::worldToMap accepts the
+ * position and |shortest_angular_distance(robot yaw, bearing to the person)| < fov_angle, float arithmetic as there. */
 typedef struct smpc_people_batch {
   int32_t B;
   int32_t Np;        /* row stride of `people`: the most persons any scene has (>= 1) */
@@ -217,6 +220,13 @@ typedef struct smpc_people_batch {
   int32_t on_device; /* 0: host pointers, 1: device pointers (outputs follow) */
   const double* people;  /* [B][Np][5] position.x, position.y, velocity.x, velocity.y, velocity.z */
   const int32_t* count;  /* [B] persons of each scene */
+  /* field-of-view filter; robot_pose == NULL: none (every person goes to people_to_status) */
+  const double* robot_pose;      /* [B][3] x, y, tf2::getYaw(orientation) */
+  double fov_angle;              /* SocialMPCController::fov_angle_ (default pi/4, :60) */
+  const double* costmap_origin;  /* [B or 1][2] Costmap2D origin */
+  int32_t costmap_shared;        /* 1: one origin for all scenes */
+  int32_t size_x, size_y;        /* Costmap2D size in cells */
+  double resolution;
 } smpc_people_batch;
 
 int smpc_people_to_status_batch(smpc_handle* h, const smpc_people_batch* in, double* init_people /* [B][N][6] */,

@@ -104,6 +104,13 @@ class SmpcPeopleBatch(C.Structure):
         ("on_device", C.c_int32),
         ("people", C.c_void_p),
         ("count", C.c_void_p),
+        ("robot_pose", C.c_void_p),
+        ("fov_angle", C.c_double),
+        ("costmap_origin", C.c_void_p),
+        ("costmap_shared", C.c_int32),
+        ("size_x", C.c_int32),
+        ("size_y", C.c_int32),
+        ("resolution", C.c_double),
     ]
 
 

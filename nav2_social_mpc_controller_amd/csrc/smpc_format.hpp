@@ -92,23 +92,61 @@ struct PeopleParams {
   const int32_t* count;   // [B]
   double* init_people;    // [B][N][6]
   uint8_t* has_people;    // [B] or null
+  // field-of-view filter (robot_pose == null: off)
+  const double* robot_pose;      // [B][3]
+  double fov_angle;
+  const double* costmap_origin;  // [B or 1][2]
+  int costmap_shared, size_x, size_y;
+  double resolution;
 };
 
-// Optimizer::people_to_status (src/optimizer.cpp:454-482): one lane per (scene, output agent).
+// angles::shortest_angular_distance(from, to) = normalize_angle(to - from) (ros/angles, ROS 2 form)
+__device__ inline double people_shortest_angular_distance(double from, double to) {
+  const double r = fmod((to - from) + M_PI, 2.0 * M_PI);
+  return (r <= 0.0) ? r + M_PI : r - M_PI;
+}
+
+// The field-of-view filter of computeVelocityCommands (src/social_mpc_controller.cpp:196-214) followed by
+// Optimizer::people_to_status (src/optimizer.cpp:454-482): one lane per scene, the persons of a scene are walked in
+// order (the filter compacts, people_to_status truncates to the first N and pads with t = -1).
 __global__ __launch_bounds__(256) void smpc_people_to_status_kernel(const PeopleParams p) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)p.B * p.N) return;
-  const int s = (int)(gid / p.N), a = (int)(gid - (long long)s * p.N);
-  const int cnt = p.count[s];
-  double* o = p.init_people + (size_t)gid * 6;
-  if (a < cnt && a < p.Np) {
-    const double* q = p.people + ((size_t)s * p.Np + a) * 5;
-    const double vx = q[2], vy = q[3];
-    o[0] = q[0]; o[1] = q[1]; o[2] = atan2(vy, vx); o[3] = 0.0; o[4] = sqrt(vx * vx + vy * vy); o[5] = q[4];
-  } else {  // "we fill with invalid agent: time=-1" (:470-476)
-    o[0] = 0.0; o[1] = 0.0; o[2] = 0.0; o[3] = -1.0; o[4] = 0.0; o[5] = 0.0;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.B) return;
+  const int cnt = min(max(p.count[s], 0), p.Np);
+  double* o = p.init_people + (size_t)s * p.N * 6;
+  const bool filter = p.robot_pose != nullptr;
+  double rx = 0, ry = 0, ox = 0, oy = 0;
+  float robot_yaw = 0.f;
+  if (filter) {
+    rx = p.robot_pose[3 * s]; ry = p.robot_pose[3 * s + 1];
+    robot_yaw = (float)p.robot_pose[3 * s + 2];
+    ox = p.costmap_origin[p.costmap_shared ? 0 : 2 * s]; oy = p.costmap_origin[p.costmap_shared ? 1 : 2 * s + 1];
   }
-  if (a == 0 && p.has_people) p.has_people[s] = cnt != 0 ? 1 : 0;
+  int kept = 0;
+  for (int a = 0; a < cnt; ++a) {
+    const double* q = p.people + ((size_t)s * p.Np + a) * 5;
+    const double px = q[0], py = q[1];
+    if (filter) {
+      // Costmap2D::worldToMap (nav2_costmap_2d): inside the map <=> not left of / below the origin and cell < size
+      if (px < ox || py < oy) continue;
+      const unsigned mx = (unsigned)(long long)((px - ox) / p.resolution), my = (unsigned)(long long)((py - oy) / p.resolution);
+      if (!(mx < (unsigned)p.size_x && my < (unsigned)p.size_y)) continue;
+      const float angle_to_person = (float)atan2(py - ry, px - rx);
+      const float relative = (float)people_shortest_angular_distance((double)robot_yaw, (double)angle_to_person);
+      if (!((double)fabsf(relative) < p.fov_angle)) continue;
+    }
+    if (kept < p.N) {
+      const double vx = q[2], vy = q[3];
+      double* r = o + (size_t)kept * 6;
+      r[0] = px; r[1] = py; r[2] = atan2(vy, vx); r[3] = 0.0; r[4] = sqrt(vx * vx + vy * vy); r[5] = q[4];
+    }
+    ++kept;
+  }
+  for (int k = min(kept, p.N); k < p.N; ++k) {  // "we fill with invalid agent: time=-1" (:470-476)
+    double* r = o + (size_t)k * 6;
+    r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = -1.0; r[4] = 0.0; r[5] = 0.0;
+  }
+  if (p.has_people) p.has_people[s] = kept != 0 ? 1 : 0;
 }
 
 struct StoreParams {

@@ -440,19 +440,29 @@ int smpc_people_to_status_batch(smpc_handle* h, const smpc_people_batch* in, dou
   smpc::PeopleParams p;
   std::memset(&p, 0, sizeof(p));
   p.B = in->B; p.Np = in->Np; p.N = in->N;
+  const bool filter = in->robot_pose != nullptr;
+  if (filter && (!in->costmap_origin || in->size_x < 1 || in->size_y < 1 || !(in->resolution > 0.0))) {
+    set_error("field-of-view filter needs the costmap geometry"); return SMPC_ERR_INVALID_ARG;
+  }
+  p.fov_angle = in->fov_angle; p.costmap_shared = in->costmap_shared; p.size_x = in->size_x; p.size_y = in->size_y;
+  p.resolution = in->resolution;
   Staging st(h);
   if (in->on_device) {
     p.people = in->people; p.count = in->count; p.init_people = init_people; p.has_people = has_people;
+    p.robot_pose = in->robot_pose; p.costmap_origin = in->costmap_origin;
   } else {
     SMPC_TRY(st.up(in->people, B * Np * 5, &p.people, h->stream));
     SMPC_TRY(st.up(in->count, B, &p.count, h->stream));
+    if (filter) {
+      SMPC_TRY(st.up(in->robot_pose, B * 3, &p.robot_pose, h->stream));
+      SMPC_TRY(st.up(in->costmap_origin, (in->costmap_shared ? 1 : B) * 2, &p.costmap_origin, h->stream));
+    }
     SMPC_TRY(st.out(init_people, B * N * 6, &p.init_people));
     SMPC_TRY(st.out(has_people, B, &p.has_people));
   }
   if (B > 0) {
-    const long long n = (long long)B * (long long)N;
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(smpc::smpc_people_to_status_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
+    hipLaunchKernelGGL(smpc::smpc_people_to_status_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

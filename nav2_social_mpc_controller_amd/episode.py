@@ -1,6 +1,8 @@
 """Closed-loop (receding-horizon) batch episodes: B independent robots, every tick runs the whole
 `Optimizer::optimize` chain of the reference on the device,
 
+    field-of-view filter + people_to_status (src/social_mpc_controller.cpp:196-214, src/optimizer.cpp:454-482)
+                                                                                   -> smpc_people_to_status_batch
     format_to_optimize + TrajectoryMemory   (src/optimizer.cpp:172-190, 484-551)  -> smpc_format_to_optimize_batch
     project_people                           (src/optimizer.cpp:554-728)           -> smpc_project_people_batch
     problem assembly + ceres::Solve + unpack (src/optimizer.cpp:197-446)           -> smpc_solve_batch
@@ -11,7 +13,9 @@ smpc_trajectorize_path_batch) as in SocialMPCController::computeVelocityCommands
 with all state resident in HBM (torch tensors are only the allocator here). What the reference gets from outside is
 stood in for by the simplest thing that has the same shape:
   * without global plans: a constant-curvature arc from the current pose in place of the trajectorizer output;
-  * the world: the robot moves to the first pose of the optimised path and takes its first command as current twist,
+  * the world: the robot executes the command computeVelocityCommands returns for one period — the first optimised
+    command (it lands on the first pose of the optimised path), the trajectorizer's first command when the solve was
+    not usable (src/social_mpc_controller.cpp:241-245), 0.1 m/s straight ahead when there is no trajectory (:180-189);
     people move with constant velocity.
 """
 import ctypes as C
@@ -19,7 +23,7 @@ from dataclasses import dataclass
 
 import numpy as np
 
-from ._abi import (SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcProjectionBatch, SmpcSceneBatch,
+from ._abi import (SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcPeopleBatch, SmpcProjectionBatch, SmpcSceneBatch,
                    SmpcTrajectorizeOut)
 from .params import OptimizerParams, TrajectorizerParams
 from .scenes import SceneBatch
@@ -43,17 +47,21 @@ class TickRecord:
     proj_error: np.ndarray
     result: dict
     memory_after: dict
-    robot_pose: np.ndarray = None   # [B,3] pose the trajectorizer started from (plan mode)
+    robot_pose: np.ndarray = None   # [B,3] pose the tick started from
     traj_n_poses: np.ndarray = None
+    persons: np.ndarray = None      # [B,Np,5] world people (px, py, vx, vy, vz) the tick started from
+    person_count: np.ndarray = None
+    has_people: np.ndarray = None
 
 
 class BatchEpisode:
     def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
                  od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
-                 plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None):
+                 plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None):
         """scenes: the start state (pose0, people at step 0, costmaps); w_ref [B]: curvature of the arc stand-in;
         od_*: one ObstacleDistance grid shared by all scenes. plan [B,L,2] + plan_len [B] + traj_params: global plans,
-        trajectorized on the device every tick (the plan must stay longer than the horizon for the whole episode)."""
+        trajectorized on the device every tick (the plan must stay longer than the horizon for the whole episode).
+        fov_angle: field-of-view half angle of the people filter (reference default pi/4); None = no filter."""
         import torch
 
         self.torch = torch
@@ -70,9 +78,17 @@ class BatchEpisode:
         self.pose = torch.from_numpy(scenes.pose0.copy()).to(self.dev)                 # [B,3] current robot pose
         self.speed = torch.from_numpy(scenes.init_params[:, 0:2].copy()).to(self.dev)  # [B,2] current twist
         self.w_ref = torch.from_numpy(np.ascontiguousarray(w_ref, np.float64)).to(self.dev)
-        # people_to_status layout [B,N,6]: x, y, yaw, t, lv, av (scene people at step 0)
-        self.people = torch.from_numpy(np.ascontiguousarray(scenes.people[:, 0].transpose(0, 2, 1))).to(self.dev)
-        self.has_people = torch.from_numpy(scenes.has_people.copy()).to(self.dev)
+        # world people as people_msgs::Person rows [B,Np,5]: position x, y, velocity x, y, z (scene people at step 0;
+        # make_scenes keeps the invalid ones at the end, so the first `count` rows are the persons)
+        st0 = scenes.people[:, 0].transpose(0, 2, 1)                                    # [B,N,6] x, y, yaw, t, lv, av
+        persons = np.stack([st0[:, :, 0], st0[:, :, 1], st0[:, :, 4] * np.cos(st0[:, :, 2]), st0[:, :, 4] * np.sin(st0[:, :, 2]),
+                            st0[:, :, 5]], axis=-1)
+        count = np.where(scenes.has_people != 0, (st0[:, :, 3] != -1.0).sum(axis=1), 0).astype(np.int32)
+        self.persons = torch.from_numpy(np.ascontiguousarray(persons)).to(self.dev)
+        self.person_count = torch.from_numpy(count).to(self.dev)
+        self.fov_angle = fov_angle
+        self.people = torch.zeros((B, N, 6), **f64)                                     # people_to_status output
+        self.has_people = torch.zeros(B, dtype=torch.uint8, device=self.dev)
         self.costmap = torch.from_numpy(scenes.costmap).to(self.dev)
         self.costmap_origin = torch.from_numpy(scenes.costmap_origin).to(self.dev)
         self.costmap_shared = scenes.costmap_shared
@@ -155,10 +171,24 @@ class BatchEpisode:
         rec = {}
         if record:
             if self.plan is not None:
-                rec.update(robot_pose=pose_before, traj_n_poses=self.traj_n.cpu().numpy().copy())
+                rec.update(traj_n_poses=self.traj_n.cpu().numpy().copy())
+            rec.update(robot_pose=pose_before, persons=self.persons.cpu().numpy().copy(),
+                       person_count=self.person_count.cpu().numpy().copy())
+        # 0. field-of-view filter + people_to_status
+        qb = SmpcPeopleBatch()
+        qb.B, qb.Np, qb.N, qb.on_device = B, int(self.persons.shape[1]), N, 1
+        qb.people, qb.count = self.persons.data_ptr(), self.person_count.data_ptr()
+        if self.fov_angle is not None:
+            qb.robot_pose, qb.fov_angle = self.pose.data_ptr(), float(self.fov_angle)
+            qb.costmap_origin, qb.costmap_shared = self.costmap_origin.data_ptr(), 1 if self.costmap_shared else 0
+            qb.size_x, qb.size_y, qb.resolution = self.size_x, self.size_y, self.resolution
+        s.people_to_status_device(qb, self.people.data_ptr(), self.has_people.data_ptr())
+        if timing is not None:
+            timing["people_ms"] = s.last_kernel_ms()
+        if record:
             rec.update(plan_path=self.plan_path.cpu().numpy().copy(), plan_cmds=self.plan_cmds.cpu().numpy().copy(),
                        speed=self.speed.cpu().numpy().copy(), init_people=self.people.cpu().numpy().copy(),
-                       memory_before=self._memory_host())
+                       has_people=self.has_people.cpu().numpy().copy(), memory_before=self._memory_host())
         # 1. format_to_optimize + memory
         fb = SmpcFormatBatch()
         fb.B, fb.T, fb.path_rows, fb.on_device = B, T, self.rows, 1
@@ -212,18 +242,23 @@ class BatchEpisode:
                        goal_yaw=self.goal_yaw.cpu().numpy().copy(), people_proj=self.people_proj.cpu().numpy().copy(),
                        proj_error=self.proj_error.cpu().numpy().copy(),
                        result={k: v.cpu().numpy().copy() for k, v in self.res.items()}, memory_after=self._memory_host())
-        # 5. the world moves one period: a failed solve keeps the robot where it is with zero twist (the controller's
-        #    fallback publishes a stop, src/social_mpc_controller.cpp:241-245)
+        # 5. the world moves one period with the command computeVelocityCommands returns: cmds[0] of a usable solve (the
+        #    robot lands on the first optimised pose), the trajectorizer's first command otherwise (:241-245), 0.1 m/s
+        #    straight ahead when trajectorize() returned false (:180-189)
         ok = (self.res["status"] != 2)
         dt = prm.dt
-        new_pose = self.res["path"][:, 0, :]
-        new_speed = self.res["cmds"][:, 0, :]
-        self.pose = torch.where(ok[:, None], new_pose, self.pose)
-        self.speed = torch.where(ok[:, None], new_speed, torch.zeros_like(self.speed))
-        moving = self.people[:, :, 3] != -1.0
-        step = self.people[:, :, 4] * dt
-        self.people[:, :, 0] += torch.where(moving, step * torch.cos(self.people[:, :, 2]), torch.zeros_like(step))
-        self.people[:, :, 1] += torch.where(moving, step * torch.sin(self.people[:, :, 2]), torch.zeros_like(step))
+        fb_pose, fb_speed = self.plan_path[:, 1, :], self.plan_cmds[:, 0, :]
+        if self.plan is not None:
+            none = (self.traj_n == 0)[:, None]
+            creep = torch.stack([self.pose[:, 0] + 0.1 * dt * torch.cos(self.pose[:, 2]),
+                                 self.pose[:, 1] + 0.1 * dt * torch.sin(self.pose[:, 2]), self.pose[:, 2]], dim=1)
+            slow = torch.zeros_like(self.speed)
+            slow[:, 0] = 0.1
+            fb_pose, fb_speed = torch.where(none, creep, fb_pose), torch.where(none, slow, fb_speed)
+        self.pose = torch.where(ok[:, None], self.res["path"][:, 0, :], fb_pose).contiguous()
+        self.speed = torch.where(ok[:, None], self.res["cmds"][:, 0, :], fb_speed).contiguous()
+        self.persons[:, :, 0] += self.persons[:, :, 2] * dt
+        self.persons[:, :, 1] += self.persons[:, :, 3] * dt
         self.ticks += 1
         return TickRecord(**rec) if record else None
 

@@ -201,15 +201,24 @@ class BatchSolver:
         assert tb.on_device == 1
         _check(self.lib, self.lib.smpc_trajectorize_path_batch(self._h, C.byref(tb), C.byref(to)), "smpc_trajectorize_path_batch")
 
-    def people_to_status(self, people: np.ndarray, count: np.ndarray, N: int = 3):
+    def people_to_status(self, people: np.ndarray, count: np.ndarray, N: int = 3, robot_pose: np.ndarray = None,
+                         fov_angle: float = np.pi / 4, costmap_origin: np.ndarray = None, size_x: int = 0, size_y: int = 0,
+                         resolution: float = 0.0):
         """Optimizer::people_to_status for B scenes: people [B,Np,5] (px, py, vx, vy, vz), count [B] ->
-        (init_people [B,N,6], has_people [B] uint8)."""
+        (init_people [B,N,6], has_people [B] uint8). With robot_pose [B,3] the field-of-view filter of
+        computeVelocityCommands runs first (costmap_origin [B or 1,2], size_x/size_y cells, resolution)."""
         people = np.ascontiguousarray(people, np.float64)
         count = np.ascontiguousarray(count, np.int32)
         B, Np, _ = people.shape
         pb = SmpcPeopleBatch()
         pb.B, pb.Np, pb.N, pb.on_device = B, Np, N, 0
         pb.people, pb.count = people.ctypes.data, count.ctypes.data
+        if robot_pose is not None:
+            robot_pose = np.ascontiguousarray(robot_pose, np.float64)
+            costmap_origin = np.ascontiguousarray(costmap_origin, np.float64).reshape(-1, 2)
+            pb.robot_pose, pb.fov_angle = robot_pose.ctypes.data, float(fov_angle)
+            pb.costmap_origin, pb.costmap_shared = costmap_origin.ctypes.data, 1 if costmap_origin.shape[0] == 1 else 0
+            pb.size_x, pb.size_y, pb.resolution = int(size_x), int(size_y), float(resolution)
         out, has = np.zeros((B, N, 6)), np.zeros(B, np.uint8)
         _check(self.lib, self.lib.smpc_people_to_status_batch(self._h, C.byref(pb), out.ctypes.data, has.ctypes.data),
                "smpc_people_to_status_batch")
@@ -271,6 +280,11 @@ class BatchSolver:
     def memory_store_device(self, B: int, T: int, status_ptr: int, path_ptr: int, cmds_ptr: int, mb: SmpcMemoryBatch):
         _check(self.lib, self.lib.smpc_memory_store_batch(self._h, B, T, 1, C.c_void_p(status_ptr), C.c_void_p(path_ptr),
                                                           C.c_void_p(cmds_ptr), C.byref(mb)), "smpc_memory_store_batch")
+
+    def people_to_status_device(self, pb: SmpcPeopleBatch, out_ptr: int, has_people_ptr: int):
+        assert pb.on_device == 1
+        _check(self.lib, self.lib.smpc_people_to_status_batch(self._h, C.byref(pb), C.c_void_p(out_ptr), C.c_void_p(has_people_ptr)),
+               "smpc_people_to_status_batch")
 
     def project_people_device(self, pb: SmpcProjectionBatch, out_ptr: int, err_ptr: int):
         assert pb.on_device == 1

@@ -77,3 +77,24 @@ def people_to_status(people, count, N=3):
             px, py, vx, vy, vz = people[s, a]
             out[s, a] = (px, py, math.atan2(vy, vx), 0.0, math.sqrt(vx * vx + vy * vy), vz)
     return out, (np.asarray(count) != 0).astype(np.uint8)
+
+
+def fov_filter(people, count, robot_pose, fov_angle, origin, size_x, size_y, resolution):
+    """The field-of-view filter of SocialMPCController::computeVelocityCommands (reference
+    src/social_mpc_controller.cpp:196-214) for one scene: returns the indices of the persons that are kept.
+    Third-party arithmetic restated: nav2_costmap_2d Costmap2D::worldToMap, angles::shortest_angular_distance (ROS 2)."""
+    keep = []
+    robot_yaw = np.float32(robot_pose[2])
+    for a in range(int(count)):
+        px, py = people[a, 0], people[a, 1]
+        if px < origin[0] or py < origin[1]:
+            continue
+        mx, my = int((px - origin[0]) / resolution), int((py - origin[1]) / resolution)
+        if not (mx < size_x and my < size_y):
+            continue
+        angle = np.float32(math.atan2(py - robot_pose[1], px - robot_pose[0]))
+        r = math.fmod((float(angle) - float(robot_yaw)) + math.pi, 2.0 * math.pi)
+        rel = np.float32(r + math.pi if r <= 0.0 else r - math.pi)
+        if float(abs(rel)) < fov_angle:
+            keep.append(a)
+    return keep

@@ -27,6 +27,9 @@ def test_episode_ticks_match_cpu_chain(oracle):
     n_checked = 0
     for tick in range(3):
         r = ep.tick(record=True)
+        # --- f2: people_to_status (no field-of-view filter in this episode)
+        st, has = pyref_format.people_to_status(r.persons, r.person_count, N)
+        assert np.max(np.abs(r.init_people - st)) <= 1e-14 and np.array_equal(r.has_people, has)
         # --- f2: format_to_optimize + memory initialisation
         mem = {k: v.copy() for k, v in r.memory_before.items()}
         exp = pyref_format.format_to_optimize(r.plan_path, r.plan_cmds, r.speed, mem, prm.current_path_weight,
@@ -45,7 +48,7 @@ def test_episode_ticks_match_cpu_chain(oracle):
             assert np.max(np.abs(got - pp)) <= 1e-9, (tick, s)
         # --- a1-a12: the solve on exactly the inputs the device assembled
         scene = SceneBatch(T, N, prm.dt, r.pose0, r.init_params, r.path_pts, r.goal_yaw,
-                           np.ascontiguousarray(r.people_proj), sc.has_people, sc.costmap, sc.costmap_origin,
+                           np.ascontiguousarray(r.people_proj), r.has_people, sc.costmap, sc.costmap_origin,
                            sc.resolution, False)
         rz = oracle.solve(prm, scene, nthreads=8, theta_zero_convention=True)
         firm = rz["marginal_decisions"] == 0
@@ -81,11 +84,21 @@ def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
     CH, bl, nb, P, M, _ = prm.dims(T, True)
     w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
     plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)  # radius >= 4.2 m: the 20 m arc never closes on itself
+    fov = 1.2  # wider than the reference default (pi/4) so that a good share of the scenes keeps somebody in view
     ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)),
-                      plan=plan, plan_len=plan_len, traj_params=tp)
+                      plan=plan, plan_len=plan_len, traj_params=tp, fov_angle=fov)
+    seen = 0
     for tick in range(3):
         r = ep.tick(record=True)
         assert (r.traj_n_poses == tp.max_steps + 1).all()
+        # f4 / f2: field-of-view filter + people_to_status from the world people and the pose the tick started from
+        for s in range(B):
+            keep = pyref_format.fov_filter(r.persons[s], r.person_count[s], r.robot_pose[s], fov, sc.costmap_origin[s],
+                                           sc.size_x, sc.size_y, sc.resolution)
+            sel = r.persons[s][keep][None] if keep else np.zeros((1, 1, 5))
+            st, has = pyref_format.people_to_status(sel, np.array([len(keep)]), N)
+            assert np.max(np.abs(r.init_people[s] - st[0])) <= 1e-14 and r.has_people[s] == has[0], (tick, s)
+            seen += len(keep)
         for s in range(0, B, 5):  # f3 on the pose the tick started from
             p, c, err = pyref_trajectorize.trajectorize(plan[s], r.robot_pose[s], tp.omnidirectional, tp.desired_linear_vel,
                                                         tp.lookahead_dist, tp.max_angular_vel, tp.time_step, tp.max_time)
@@ -100,10 +113,11 @@ def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
             err = np.abs(getattr(r, k) - exp[k])
             assert np.max(np.minimum(err, np.abs(err - 2 * np.pi))) <= 1e-13, (tick, k)
         scene = SceneBatch(T, N, prm.dt, r.pose0, r.init_params, r.path_pts, r.goal_yaw,
-                           np.ascontiguousarray(r.people_proj), sc.has_people, sc.costmap, sc.costmap_origin,
+                           np.ascontiguousarray(r.people_proj), r.has_people, sc.costmap, sc.costmap_origin,
                            sc.resolution, False)
         rz = oracle.solve(prm, scene, nthreads=8, theta_zero_convention=True)
         firm = rz["marginal_decisions"] == 0
         err = np.max(np.abs(r.result["cmds"] - rz["cmds"]).reshape(B, -1), axis=1)
         assert firm.mean() >= 0.8 and np.max(err[firm]) <= CMD_TOL, (tick, float(np.max(err[firm])))
     assert np.max(np.abs(ep.pose.cpu().numpy()[:, :2] - sc.pose0[:, :2])) > 0.02
+    assert 0 < seen < 3 * B * 2   # the filter kept some persons and dropped some

@@ -166,3 +166,53 @@ def test_gpu_people_to_status_matches_pyref(N):
     got, has = BatchSolver(OptimizerParams.readme()).people_to_status(people, count, N)
     exp, ehas = pyref_format.people_to_status(people, count, N)
     assert np.array_equal(has, ehas) and np.max(np.abs(got - exp)) <= 1e-14
+
+
+def fov_case(seed, B=200, Np=8):
+    rng = np.random.default_rng(seed)
+    pose = np.stack([rng.uniform(3, 7, B), rng.uniform(3, 7, B), rng.uniform(-np.pi, np.pi, B)], 1)
+    people = rng.normal(size=(B, Np, 5))
+    r, phi = rng.uniform(0.5, 6.0, (B, Np)), rng.uniform(-np.pi, np.pi, (B, Np))
+    people[:, :, 0] = pose[:, None, 0] + r * np.cos(phi)
+    people[:, :, 1] = pose[:, None, 1] + r * np.sin(phi)
+    count = rng.integers(0, Np + 1, size=B).astype(np.int32)
+    origin = np.array([[0.0, 0.0]])
+    return pose, people, count, origin, 200, 200, 0.05   # 10 m x 10 m costmap: some persons fall outside
+
+
+def pyref_fov_status(pose, people, count, origin, sx, sy, res, fov, N):
+    from oracle import pyref_format
+    B = pose.shape[0]
+    st, has = np.zeros((B, N, 6)), np.zeros(B, np.uint8)
+    kept = []
+    for s in range(B):
+        keep = pyref_format.fov_filter(people[s], count[s], pose[s], fov, origin[0], sx, sy, res)
+        kept.append(len(keep))
+        sel = people[s][keep][None] if keep else np.zeros((1, 1, 5))
+        o, h = pyref_format.people_to_status(sel, np.array([len(keep)]), N)
+        st[s], has[s] = o[0], h[0]
+    return st, has, np.array(kept)
+
+
+def test_pyref_fov_filter_keeps_only_people_ahead_and_on_the_map():
+    pose, people, count, origin, sx, sy, res = fov_case(21, B=50)
+    st, has, kept = pyref_fov_status(pose, people, count, origin, sx, sy, res, np.pi / 4, 3)
+    assert 0 < kept.sum() < count.sum() and (kept <= count).all()
+    for s in range(50):
+        for a in range(min(kept[s], 3)):
+            bearing = np.arctan2(st[s, a, 1] - pose[s, 1], st[s, a, 0] - pose[s, 0])
+            d = (bearing - pose[s, 2] + np.pi) % (2 * np.pi) - np.pi
+            assert abs(d) < np.pi / 4 + 1e-6 and 0 <= st[s, a, 0] < 10 and 0 <= st[s, a, 1] < 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fov", [np.pi / 4, 1.3])
+def test_gpu_fov_filter_matches_pyref(fov):
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    pose, people, count, origin, sx, sy, res = fov_case(22)
+    got, has = BatchSolver(OptimizerParams.readme()).people_to_status(people, count, 3, robot_pose=pose, fov_angle=fov,
+                                                                      costmap_origin=origin, size_x=sx, size_y=sy, resolution=res)
+    exp, ehas, kept = pyref_fov_status(pose, people, count, origin, sx, sy, res, fov, 3)
+    assert np.array_equal(has, ehas) and np.max(np.abs(got - exp)) <= 1e-14
+    assert (kept == 0).any() and (kept > 3).any()

@@ -69,3 +69,53 @@ def test_optimize_closed_loop_matches_oracle(built, oracle, tmp_path):
         assert np.max(np.abs(ref["path"][0][:, :2].ravel() - d["path"].reshape(-1, 3)[:, :2].ravel())) <= 1e-5
         # third agent is a phantom (2 people in the demo), padded exactly like people_to_status does
         assert np.all(sc.people[0, :, 3, 2] == -1.0)
+
+
+def test_host_fov_filter_matches_numpy_restatement(built):
+    """The field-of-view filter of computeVelocityCommands (src/social_mpc_controller.cpp:196-214): C++ host mirror vs
+    oracle/pyref_format.fov_filter."""
+    import ctypes as C
+    from oracle import pyref_format
+    lib = C.CDLL(os.path.join(built, "libsmpc_host.so"))
+    lib.smpc_host_fov_filter.restype = C.c_int
+    lib.smpc_host_fov_filter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                         C.c_double, C.c_void_p]
+    rng = np.random.default_rng(5)
+    seen_in, seen_out = 0, 0
+    for _ in range(40):
+        pose = np.array([rng.uniform(3, 7), rng.uniform(3, 7), rng.uniform(-np.pi, np.pi)])
+        n = 12
+        r, phi = rng.uniform(0.5, 6.0, n), rng.uniform(-np.pi, np.pi, n)
+        xy = np.ascontiguousarray(np.stack([pose[0] + r * np.cos(phi), pose[1] + r * np.sin(phi)], 1))
+        keep = np.zeros(n, np.int32)
+        k = lib.smpc_host_fov_filter(xy.ctypes.data, n, pose.ctypes.data, np.pi / 4, 0.0, 0.0, 200, 200, 0.05, keep.ctypes.data)
+        people = np.zeros((n, 5)); people[:, :2] = xy
+        want = pyref_format.fov_filter(people, n, pose, np.pi / 4, (0.0, 0.0), 200, 200, 0.05)
+        assert k == len(want) and np.flatnonzero(keep).tolist() == want
+        seen_in += k; seen_out += n - k
+    assert seen_in > 20 and seen_out > 200
+
+
+@pytest.mark.gpu
+def test_controller_ticks_match_oracle(built, oracle, tmp_path):
+    """Three control ticks through the host mirror of SocialMPCController::computeVelocityCommands (trajectorize ->
+    field-of-view filter -> optimize -> first command); every tick's solve is replayed through the CPU oracle."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.scenes import SceneBatch
+    prefix = str(tmp_path / "ctl")
+    out = subprocess.check_output([os.path.join(built, "controller_demo"), "3", prefix], text=True)
+    lines = [l for l in out.splitlines() if l.startswith("tick")]
+    assert len(lines) == 3 and all("optimized=1" in l and "people_in_fov=1" in l for l in lines)   # 1 of 3 persons is seen
+    prm = OptimizerParams.readme()
+    for tick in range(3):
+        d = _read_dump(f"{prefix}_{tick}.bin")
+        assert (d["T"], d["N"], d["P"], d["hp"]) == (28, 3, 6, 1)      # 31 trajectorized poses cut to 29
+        sc = SceneBatch(d["T"], d["N"], float(d["dt"]), d["pose0"][None], d["init"][None], d["pts"].reshape(1, -1, 2),
+                        np.array([d["goal"]]), d["ppl"].reshape(1, d["T"] + 1, 6, d["N"]), np.array([d["hp"]], np.uint8),
+                        d["cm"].reshape(1, d["sy"], d["sx"]), d["origin"][None], float(d["res"]), True)
+        ref = oracle.solve(prm, sc, theta_zero_convention=True)
+        assert ref["status"][0] == d["status"] and ref["iterations"][0] == d["iters"]
+        assert np.max(np.abs(ref["cmds"][0].ravel() - d["cmds"])) <= 1e-5
+        assert np.all(sc.people[0, :, 3, 1:] == -1.0)                   # two phantoms: only the person ahead passed the filter
+        cmd = [float(v) for v in lines[tick].split("cmd=(")[1].split(")")[0].split(",")]
+        assert abs(cmd[0] - d["cmds"][0]) <= 1e-9 and abs(cmd[1] - d["cmds"][1]) <= 1e-9   # the command returned = cmds[0]
