@@ -18,6 +18,15 @@ geometry_msgs::msg::Quaternion from_yaw(double yaw)
   q.x = 0.0; q.y = 0.0; q.z = std::sin(yaw * 0.5); q.w = std::cos(yaw * 0.5);
   return q;
 }
+// One explicit-Euler step of the motion model (path_trajectorizer.hpp:106-135): body-frame velocity (vx, vy) rotated by
+// theta — the lateral axis written as an angle of theta + pi/2 like the reference — and the heading advanced by wz.
+struct Pose2 { double x, y, theta; };
+Pose2 advance(const Pose2 & p, double vx, double vy, double wz, double dt)
+{
+  const double c = std::cos(p.theta), s = std::sin(p.theta);
+  const double cl = std::cos(M_PI_2 + p.theta), sl = std::sin(M_PI_2 + p.theta);
+  return Pose2{p.x + (vx * c + vy * cl) * dt, p.y + (vx * s + vy * sl) * dt, p.theta + wz * dt};
+}
 // angles::normalize_angle (ros/angles, ROS 2 form)
 double normalize_angle(double a)
 {
@@ -81,9 +90,8 @@ bool PathTrajectorizer::trajectorize(
         wz = vx * curvature;
       }
     }
-    rx = computeNewXPosition(rx, vx, vy, rtheta, time_step_);
-    ry = computeNewYPosition(ry, vx, vy, rtheta, time_step_);
-    rtheta = computeNewThetaPosition(rtheta, wz, time_step_);
+    const Pose2 next = advance(Pose2{rx, ry, rtheta}, vx, vy, wz, time_step_);
+    rx = next.x; ry = next.y; rtheta = next.theta;
     robot_pose.pose.position.x = rx;
     robot_pose.pose.position.y = ry;
     robot_pose.pose.orientation = from_yaw(rtheta);

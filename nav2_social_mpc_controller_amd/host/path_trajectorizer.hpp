@@ -39,17 +39,8 @@ public:
 
   float inline getTimeStep() { return time_step_; }
 
-protected:
-  inline double computeNewXPosition(double xi, double vx, double vy, double theta, double dt)
-  {
-    return xi + (vx * std::cos(theta) + vy * std::cos(M_PI_2 + theta)) * dt;
-  }
-  inline double computeNewYPosition(double yi, double vx, double vy, double theta, double dt)
-  {
-    return yi + (vx * std::sin(theta) + vy * std::sin(M_PI_2 + theta)) * dt;
-  }
-  inline double computeNewThetaPosition(double thetai, double vth, double dt) { return thetai + vth * dt; }
-
+private:
+  // pure-pursuit parameters (configure); the unicycle / holonomic step of path_trajectorizer.hpp:106-135 lives in the .cpp
   double desired_linear_vel_ = 0.4;
   double lookahead_dist_ = 0.4;
   double max_angular_vel_ = 1.0;
