@@ -112,3 +112,28 @@ def trace(params, scenes, scene=0, max_rows=256):
     if n < 0:
         raise RuntimeError(f"smpc_oracle_solve_trace failed: {n}")
     return rows[:min(n, max_rows)]
+
+
+OP_NAMES = ["add", "mul", "div", "sqrt", "exp", "sincos", "atan2"]
+_count_lib = None
+
+
+def count_ops(params, scenes, scene=0, x=None):
+    """Scalar FP64 operations of the Jet passes of ONE Jacobian evaluation in the reference's formulation
+    (DynamicAutoDiffCostFunction on ceres::Jet<double, 4>), counted by an instrumented build of the oracle
+    (oracle/_build/libsmpc_oracle_count.so). Returns a dict name -> count."""
+    global _count_lib
+    if _count_lib is None:
+        path = os.path.join(_HERE, "_build", "libsmpc_oracle_count.so")
+        if not os.path.exists(path):
+            build()
+        _count_lib = C.CDLL(path)
+        _count_lib.smpc_oracle_count_ops.restype = C.c_int
+        _count_lib.smpc_oracle_count_ops.argtypes = [C.POINTER(SmpcParams), C.POINTER(SmpcSceneBatch), C.c_int, C.c_void_p, C.c_void_p]
+    x = np.ascontiguousarray(scenes.init_params[scene] if x is None else x, dtype=np.float64)
+    out = np.zeros(7, dtype=np.int64)
+    cp, sb = params.to_c(), scenes.to_c()
+    rc = _count_lib.smpc_oracle_count_ops(C.byref(cp), C.byref(sb), int(scene), x.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"smpc_oracle_count_ops failed: {rc}")
+    return dict(zip(OP_NAMES, (int(v) for v in out)))

@@ -36,6 +36,18 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int kStride = 4;  // DynamicAutoDiffCostFunction<F, Stride = 4>
 
+// Operation counting (the FP64 work of one Jacobian evaluation in the reference's formulation, i.e. what
+// DynamicAutoDiffCostFunction executes on Jets). Compiled in only with -DSMPC_ORACLE_COUNT_OPS (a second library,
+// oracle/_build/libsmpc_oracle_count.so); the timed oracle carries none of it. Counts are per scalar operation:
+// a Jet product is 1 + 2*4 multiplies and 4 adds, and so on.
+#ifdef SMPC_ORACLE_COUNT_OPS
+struct OpCount { long add, mul, div, sqrt, exp, sincos, atan2; };
+thread_local OpCount g_ops = {0, 0, 0, 0, 0, 0, 0};
+#define SMPC_OPS(field, n) (g_ops.field += (n))
+#else
+#define SMPC_OPS(field, n) ((void)0)
+#endif
+
 struct Jet {
   double a;
   double v[kStride];
@@ -43,29 +55,30 @@ struct Jet {
   Jet(double s) : a(s) { for (double& t : v) t = 0.0; }  // NOLINT implicit, like ceres::Jet
 };
 
-inline Jet operator+(const Jet& f, const Jet& g) { Jet h; h.a = f.a + g.a; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] + g.v[k]; return h; }
-inline Jet operator-(const Jet& f, const Jet& g) { Jet h; h.a = f.a - g.a; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] - g.v[k]; return h; }
+inline Jet operator+(const Jet& f, const Jet& g) { SMPC_OPS(add, 1 + kStride); Jet h; h.a = f.a + g.a; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] + g.v[k]; return h; }
+inline Jet operator-(const Jet& f, const Jet& g) { SMPC_OPS(add, 1 + kStride); Jet h; h.a = f.a - g.a; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] - g.v[k]; return h; }
 inline Jet operator-(const Jet& f) { Jet h; h.a = -f.a; for (int k = 0; k < kStride; ++k) h.v[k] = -f.v[k]; return h; }
-inline Jet operator*(const Jet& f, const Jet& g) { Jet h; h.a = f.a * g.a; for (int k = 0; k < kStride; ++k) h.v[k] = f.a * g.v[k] + f.v[k] * g.a; return h; }
+inline Jet operator*(const Jet& f, const Jet& g) { SMPC_OPS(mul, 1 + 2 * kStride); SMPC_OPS(add, kStride); Jet h; h.a = f.a * g.a; for (int k = 0; k < kStride; ++k) h.v[k] = f.a * g.v[k] + f.v[k] * g.a; return h; }
 inline Jet operator/(const Jet& f, const Jet& g) {
+  SMPC_OPS(div, 1); SMPC_OPS(mul, 1 + 2 * kStride); SMPC_OPS(add, kStride);
   const double g_inv = 1.0 / g.a;
   const double q = f.a * g_inv;
   Jet h; h.a = q;
   for (int k = 0; k < kStride; ++k) h.v[k] = (f.v[k] - q * g.v[k]) * g_inv;
   return h;
 }
-inline Jet operator+(const Jet& f, double s) { Jet h = f; h.a = f.a + s; return h; }
-inline Jet operator+(double s, const Jet& f) { Jet h = f; h.a = f.a + s; return h; }
-inline Jet operator-(const Jet& f, double s) { Jet h = f; h.a = f.a - s; return h; }
-inline Jet operator-(double s, const Jet& f) { Jet h; h.a = s - f.a; for (int k = 0; k < kStride; ++k) h.v[k] = -f.v[k]; return h; }
-inline Jet operator*(const Jet& f, double s) { Jet h; h.a = f.a * s; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] * s; return h; }
+inline Jet operator+(const Jet& f, double s) { SMPC_OPS(add, 1); Jet h = f; h.a = f.a + s; return h; }
+inline Jet operator+(double s, const Jet& f) { SMPC_OPS(add, 1); Jet h = f; h.a = f.a + s; return h; }
+inline Jet operator-(const Jet& f, double s) { SMPC_OPS(add, 1); Jet h = f; h.a = f.a - s; return h; }
+inline Jet operator-(double s, const Jet& f) { SMPC_OPS(add, 1); Jet h; h.a = s - f.a; for (int k = 0; k < kStride; ++k) h.v[k] = -f.v[k]; return h; }
+inline Jet operator*(const Jet& f, double s) { SMPC_OPS(mul, 1 + kStride); Jet h; h.a = f.a * s; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] * s; return h; }
 inline Jet operator*(double s, const Jet& f) { return f * s; }
-inline Jet operator/(const Jet& f, double s) { const double si = 1.0 / s; Jet h; h.a = f.a * si; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] * si; return h; }
-inline Jet operator/(double s, const Jet& g) { const double m = -s / (g.a * g.a); Jet h; h.a = s / g.a; for (int k = 0; k < kStride; ++k) h.v[k] = g.v[k] * m; return h; }
+inline Jet operator/(const Jet& f, double s) { SMPC_OPS(div, 1); SMPC_OPS(mul, 1 + kStride); const double si = 1.0 / s; Jet h; h.a = f.a * si; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] * si; return h; }
+inline Jet operator/(double s, const Jet& g) { SMPC_OPS(div, 2); SMPC_OPS(mul, 1 + kStride); const double m = -s / (g.a * g.a); Jet h; h.a = s / g.a; for (int k = 0; k < kStride; ++k) h.v[k] = g.v[k] * m; return h; }
 inline Jet& operator+=(Jet& f, const Jet& g) { f = f + g; return f; }
 inline Jet& operator-=(Jet& f, const Jet& g) { f = f - g; return f; }
-inline Jet& operator+=(Jet& f, double s) { f.a += s; return f; }
-inline Jet& operator-=(Jet& f, double s) { f.a -= s; return f; }
+inline Jet& operator+=(Jet& f, double s) { SMPC_OPS(add, 1); f.a += s; return f; }
+inline Jet& operator-=(Jet& f, double s) { SMPC_OPS(add, 1); f.a -= s; return f; }
 inline bool operator<(const Jet& f, const Jet& g) { return f.a < g.a; }
 inline bool operator>(const Jet& f, const Jet& g) { return f.a > g.a; }
 inline bool operator<=(const Jet& f, const Jet& g) { return f.a <= g.a; }
@@ -82,11 +95,12 @@ inline double Exp(double x) { return std::exp(x); }
 inline double Sin(double x) { return std::sin(x); }
 inline double Cos(double x) { return std::cos(x); }
 inline double Atan2(double y, double x) { return std::atan2(y, x); }
-inline Jet Sqrt(const Jet& f) { const double t = std::sqrt(f.a); const double m = 1.0 / (2.0 * t); Jet h; h.a = t; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] * m; return h; }
-inline Jet Exp(const Jet& f) { const double t = std::exp(f.a); Jet h; h.a = t; for (int k = 0; k < kStride; ++k) h.v[k] = t * f.v[k]; return h; }
-inline Jet Sin(const Jet& f) { const double c = std::cos(f.a); Jet h; h.a = std::sin(f.a); for (int k = 0; k < kStride; ++k) h.v[k] = c * f.v[k]; return h; }
-inline Jet Cos(const Jet& f) { const double s = -std::sin(f.a); Jet h; h.a = std::cos(f.a); for (int k = 0; k < kStride; ++k) h.v[k] = s * f.v[k]; return h; }
+inline Jet Sqrt(const Jet& f) { SMPC_OPS(sqrt, 1); SMPC_OPS(div, 1); SMPC_OPS(mul, 1 + kStride); const double t = std::sqrt(f.a); const double m = 1.0 / (2.0 * t); Jet h; h.a = t; for (int k = 0; k < kStride; ++k) h.v[k] = f.v[k] * m; return h; }
+inline Jet Exp(const Jet& f) { SMPC_OPS(exp, 1); SMPC_OPS(mul, kStride); const double t = std::exp(f.a); Jet h; h.a = t; for (int k = 0; k < kStride; ++k) h.v[k] = t * f.v[k]; return h; }
+inline Jet Sin(const Jet& f) { SMPC_OPS(sincos, 2); SMPC_OPS(mul, kStride); const double c = std::cos(f.a); Jet h; h.a = std::sin(f.a); for (int k = 0; k < kStride; ++k) h.v[k] = c * f.v[k]; return h; }
+inline Jet Cos(const Jet& f) { SMPC_OPS(sincos, 2); SMPC_OPS(mul, kStride); const double s = -std::sin(f.a); Jet h; h.a = std::cos(f.a); for (int k = 0; k < kStride; ++k) h.v[k] = s * f.v[k]; return h; }
 inline Jet Atan2(const Jet& g, const Jet& f) {  // atan2(y = g, x = f)
+  SMPC_OPS(atan2, 1); SMPC_OPS(div, 1); SMPC_OPS(mul, 2 + 3 * kStride); SMPC_OPS(add, 1 + kStride);
   const double t = 1.0 / (f.a * f.a + g.a * g.a);
   Jet h; h.a = std::atan2(g.a, f.a);
   for (int k = 0; k < kStride; ++k) h.v[k] = t * (-g.a * f.v[k] + f.a * g.v[k]);
@@ -1131,6 +1145,26 @@ int smpc_oracle_eval_batch(const smpc_params* prm, const smpc_scene_batch* sb, c
     if (out->gradient) std::memcpy(out->gradient + static_cast<size_t>(b) * P, g.data(), sizeof(double) * P);
   }
   return SMPC_OK;
+}
+
+// Scalar FP64 operations of the Jet passes of ONE Jacobian evaluation of scene `scene` (the residual-only double pass
+// is not instrumented). out[7] = add, mul, div, sqrt, exp, sin/cos, atan2. -1 unless built with SMPC_ORACLE_COUNT_OPS.
+int smpc_oracle_count_ops(const smpc_params* prm, const smpc_scene_batch* sb, int scene, const double* params, long* out) {
+#ifdef SMPC_ORACLE_COUNT_OPS
+  if (!prm || !sb || !params || !out || scene < 0 || scene >= sb->B) return SMPC_ERR_INVALID_ARG;
+  Scene s;
+  if (!MakeScene(prm, sb, scene, &s)) return SMPC_ERR_UNSUPPORTED;
+  std::vector<Block> blocks = BuildBlocks(s.d);
+  std::vector<double> r(s.d.M), J(static_cast<size_t>(s.d.M) * s.d.P), g(s.d.P);
+  double cost;
+  g_ops = OpCount{0, 0, 0, 0, 0, 0, 0};
+  Evaluate(s, blocks, params, r.data(), J.data(), &cost, g.data());
+  out[0] = g_ops.add; out[1] = g_ops.mul; out[2] = g_ops.div; out[3] = g_ops.sqrt; out[4] = g_ops.exp; out[5] = g_ops.sincos; out[6] = g_ops.atan2;
+  return SMPC_OK;
+#else
+  (void)prm; (void)sb; (void)scene; (void)params; (void)out;
+  return -1;
+#endif
 }
 
 // diagnostics of the polynomial root finder (single-threaded runs): out[0] = calls, out[1] = total iterations

@@ -205,3 +205,16 @@ def test_lm_reaches_the_optimum_an_unrelated_solver_finds(oracle):
         close += abs(ratio[-1] - 1.0) <= 0.01
     assert close >= 8, f"only {close}/12 scenes within 1% of scipy's optimum: {np.round(ratio, 3)}"
     assert max(ratio) <= 1.6 and min(ratio) >= 0.6
+
+
+def test_op_count_of_one_jacobian_evaluation(oracle):
+    """scalar FP64 operations of one Jacobian evaluation in the reference's formulation (Jets of stride 4),
+    counted by the instrumented oracle build. Pins the published figure's order of magnitude and its growth with N."""
+    prm = OptimizerParams.readme()
+    c8 = oracle.count_ops(prm, make_scenes(prm, 2, 8, map_cells=80, seed=5), 0)
+    c4 = oracle.count_ops(prm, make_scenes(prm, 2, 4, map_cells=80, seed=5), 0)
+    c0 = oracle.count_ops(prm, make_scenes(prm, 2, 1, map_cells=80, seed=5, people_present=False), 0)
+    flops = lambda c: c["add"] + c["mul"] + c["div"]
+    assert 0.7e6 <= flops(c8) <= 1.3e6            # SURVEY's estimate for N = 8, T = 28
+    assert flops(c0) < flops(c4) < flops(c8) and c0["exp"] == 0 and c8["exp"] > c4["exp"] > 0
+    assert c8["atan2"] >= 2 * 8 * 28              # two atan2 per directed robot-agent force
