@@ -13,5 +13,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/episode_trace" -- 
 grep -E "^\"Name\"|smpc" $(find "$OUT/episode_trace" -name "*kernel_stats.csv" | head -1) > "$OUT/${TAG}_episode_kernel_stats.csv"
 tools/prof_pmc.sh "$OUT/pmc" > /dev/null 2>&1
 cp "$OUT/pmc/pmc_summary.txt" "$OUT/${TAG}_pmc_summary.txt"
-python3 bench.py --steps 10 --warmup 2 > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
+python3 bench.py > "$OUT/${TAG}_bench.json" 2> "$OUT/bench.err"
 head -c 1500 "$OUT/${TAG}_bench_kernel_stats.csv"; echo; cat "$OUT/${TAG}_pmc_summary.txt" | grep -E "==|FETCH|WRITE|SQ_INSTS_VALU |SQ_INSTS_MFMA|SQ_WAVES|GRBM"; cat "$OUT/${TAG}_bench.json"
