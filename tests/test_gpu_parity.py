@@ -48,6 +48,11 @@ EVAL_CASES = {
     # the largest supported shape: T = 63 rollout steps (max_time 3.25 s), 64 agents (K1 stages 129 KB of people in LDS)
     "max_T63_N64": (README.replace(max_time=3.25), dict(B=4, N=64, seed=112, map_cells=120)),
     "n33_needs_wide_slot": (README, dict(B=6, N=33, seed=113, map_cells=120)),
+    # slot-width boundaries: T + 1 = 32 poses and N = 32 agents still share a wave between two scenes, one more does not
+    "t31_last_two_slot_shape": (README.replace(max_time=1.65), dict(B=6, N=5, seed=114, map_cells=100)),
+    "t32_first_one_slot_shape": (README.replace(max_time=1.70), dict(B=6, N=5, seed=115, map_cells=100)),
+    "n32_last_two_slot_shape": (README, dict(B=6, N=32, seed=116, map_cells=120)),
+    "t1_shortest_horizon": (README, dict(B=6, N=3, T=1, seed=117, map_cells=80)),
 }
 
 
@@ -111,6 +116,9 @@ SOLVE_CASES = {
     "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=64, N=5, seed=209)),
     "w32_five_blocks_valu_gram": (README.replace(parameter_block_length=4), dict(B=128, N=6, seed=210)),
     "max_T63_N64": (README.replace(max_time=3.25), dict(B=24, N=64, seed=212, map_cells=120)),
+    "t31_last_two_slot_shape": (README.replace(max_time=1.65), dict(B=48, N=5, seed=214, map_cells=100)),
+    "t32_first_one_slot_shape": (README.replace(max_time=1.70), dict(B=48, N=5, seed=215, map_cells=100)),
+    "n32_last_two_slot_shape": (README, dict(B=32, N=32, seed=216, map_cells=120, standing_fraction=0.0)),
 }
 
 
