@@ -89,8 +89,9 @@ def test_hip_projection_matches_restatements(hostlib):
     from nav2_social_mpc_controller_amd.params import OptimizerParams
     from nav2_social_mpc_controller_amd.solver import BatchSolver
     s = BatchSolver(OptimizerParams.readme())
-    for N, n_valid in ((3, 2), (3, 3), (3, 0), (8, 6), (16, 16)):
-        cases = [make_case(100 + 7 * N + i, N=N, n_valid=n_valid) for i in range(6)]
+    # N + 1 lanes per scene rounded up to a power of two: 4, 16, 32 and (N = 40, 63) the whole wavefront
+    for N, n_valid in ((3, 2), (3, 3), (3, 0), (8, 6), (16, 16), (40, 37), (63, 63)):
+        cases = [make_case(100 + 7 * N + i, N=N, n_valid=n_valid) for i in range(6 if N <= 16 else 2)]
         init = np.stack([c["init"] for c in cases])
         path = np.stack([c["path"] for c in cases])
         idx = np.stack([c["idx"] for c in cases])
