@@ -203,37 +203,48 @@ __device__ inline Force social_force(double dx, double dy, double ux, double uy)
   const double fv = -E1, fa = -sgn * E2;
   R.fx = k * (fv * ix - fa * iy);  // :218-224, i_perp = (-iy, ix)
   R.fy = k * (fv * iy + fa * ix);
-  // Directional derivative along a direction that moves n by dn, alpha = atan2(e) by dalpha, iv by (divx, divy):
-  //   dL = i . div,  kappa = d atan2(i) = (i_perp . div) / L,  dphi = dalpha - kappa,  dB = gamma dL,
-  //   d(arg_m) = -dn/B + n dB/B^2 - 2 a_m c_m (dB phi + B dphi),
-  //   dF = k ((dfv - fa kappa) i + (dfa + fv kappa) i_perp).
+  // The force depends on its inputs through (n, alpha = atan2(e), iv): dF = A_n dn + A_alpha dalpha + A_x d(iv_x) +
+  // A_y d(iv_y). With dL = i . d(iv), kappa = d atan2(i) = (i_perp . d(iv)) / L, dphi = dalpha - kappa, dB = gamma dL,
+  //   d(arg_m) = -dn/B + n dB/B^2 - 2 a_m c_m (dB phi + B dphi),   dF = k ((dfv - fa kappa) i + (dfa + fv kappa) i_perp),
+  // the four columns are evaluated once and every direction below is a linear combination of them.
   const double nB2 = n * inv_B * inv_B;
-  auto dirderiv = [&](double dn, double dalpha, double divx, double divy, double& ofx, double& ofy) {
-    const double dL = ix * divx + iy * divy;
-    const double kappa = (ix * divy - iy * divx) * inv_L;
-    const double dphi = dalpha - kappa;
+  // A_n: dn = 1 -> d(arg) = -1/B, no rotation: -F / B
+  const double anx = -inv_B * R.fx, any = -inv_B * R.fy;
+  // A_alpha: dalpha = 1 -> dphi = 1, d(arg_m) = -2 a_m c_m B
+  double aax, aay;
+  {
+    const double twoB = 2.0 * Bq;
+    const double dfv = E1 * (a1 * nPrime * twoB);
+    const double dfa = sgn * E2 * (a2 * nn * twoB);
+    aax = k * (dfv * ix - dfa * iy);
+    aay = k * (dfv * iy + dfa * ix);
+  }
+  // A_x, A_y: d(iv) = (1, 0) / (0, 1)
+  auto column = [&](double dL, double kappa, double& ofx, double& ofy) {
     const double dB = gamma * dL;
-    const double dbase = nB2 * dB - dn * inv_B;
-    const double common = dB * phi + Bq * dphi;
-    const double darg1 = dbase - 2.0 * a1 * nPrime * common;
-    const double darg2 = dbase - 2.0 * a2 * nn * common;
-    const double dfv = -E1 * darg1;
-    const double dfa = -sgn * E2 * darg2;
+    const double dbase = nB2 * dB;
+    const double common = dB * phi - Bq * kappa;  // dphi = -kappa
+    const double dfv = -E1 * (dbase - 2.0 * a1 * nPrime * common);
+    const double dfa = -sgn * E2 * (dbase - 2.0 * a2 * nn * common);
     const double ci = dfv - fa * kappa, cp = dfa + fv * kappa;
     ofx = k * (ci * ix - cp * iy);
     ofy = k * (ci * iy + cp * ix);
   };
+  double axx, axy, ayx, ayy;
+  column(ix, -iy * inv_L, axx, axy);
+  column(iy, ix * inv_L, ayx, ayy);
+  R.dfx_dux = lambda * axx; R.dfy_dux = lambda * axy;  // u enters iv as lambda u
+  R.dfx_duy = lambda * ayx; R.dfy_duy = lambda * ayy;
   if (degenerate) {
     R.dfx_dx = R.dfy_dx = R.dfx_dy = R.dfy_dy = 0.0;
   } else {
-    // dd = (1,0): dn = ex, dalpha = -ey/n, d(iv) = de = e_perp * dalpha, e_perp = (-ey, ex)
-    double da = -ey * inv_n;
-    dirderiv(ex, da, -ey * da, ex * da, R.dfx_dx, R.dfy_dx);
-    da = ex * inv_n;  // dd = (0,1)
-    dirderiv(ey, da, -ey * da, ex * da, R.dfx_dy, R.dfy_dy);
+    // moving diff by dd: dn = e . dd, dalpha = (e_perp . dd) / n, d(iv) = de = e_perp dalpha, e_perp = (-ey, ex);
+    // C = A_alpha + A_x (-ey) + A_y ex is what one unit of dalpha does in total
+    const double cx = aax - ey * axx + ex * ayx, cy = aay - ey * axy + ex * ayy;
+    const double da1 = -ey * inv_n, da2 = ex * inv_n;  // dd = (1, 0) / (0, 1)
+    R.dfx_dx = ex * anx + da1 * cx; R.dfy_dx = ex * any + da1 * cy;
+    R.dfx_dy = ey * anx + da2 * cx; R.dfy_dy = ey * any + da2 * cy;
   }
-  dirderiv(0.0, 0.0, lambda, 0.0, R.dfx_dux, R.dfy_dux);
-  dirderiv(0.0, 0.0, 0.0, lambda, R.dfx_duy, R.dfy_duy);
   return R;
 }
 
