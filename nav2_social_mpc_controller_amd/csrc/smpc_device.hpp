@@ -163,19 +163,27 @@ struct Force {
   double dfx_dux, dfy_dux, dfx_duy, dfy_duy;  // wrt u
 };
 
+// 1/sqrt(x) for a normal positive x: hardware estimate + one cubic correction (what the library routine does, without
+// its zero / infinity / denormal cases, which cannot occur here: d2 >= 1e-12 after the coincident-pair clamp, and a
+// vanishing interaction vector is a singular configuration for the reference as well).
+__device__ inline double fast_rsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+
 __device__ inline Force social_force(double dx, double dy, double ux, double uy) {
   const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, nn = 2.0, k = 2.1;
   Force R;
   double d2 = dx * dx + dy * dy;
   const bool degenerate = d2 < 1e-12;  // |diff| < 1e-6 (:181-184): diff := (1e-6, 0), a constant: no dependence on positions
   if (degenerate) { dx = 1e-6; dy = 0.0; d2 = 1e-12; }
-  const double inv_n = rsqrt(d2);
+  const double inv_n = fast_rsqrt(d2);
   const double n = d2 * inv_n;
   const double ex = dx * inv_n, ey = dy * inv_n;  // diffDirection :185
-  const double lux = lambda * ux, luy = lambda * uy;
-  const double ivx = lux + ex, ivy = luy + ey;  // :191-192
+  const double ivx = fma(lambda, ux, ex), ivy = fma(lambda, uy, ey);  // :191-192 (lambda u is exact: lambda = 2)
   const double L2 = ivx * ivx + ivy * ivy;
-  const double inv_L = rsqrt(L2);
+  const double inv_L = fast_rsqrt(L2);
   const double L = L2 * inv_L;  // :194
   const double ix = ivx * inv_L, iy = ivy * inv_L;  // :195-196
   // theta = wrapToPi(atan2(dir) - atan2(idir)) (:198-200) is the angle from idir to dir = atan2(idir x dir, idir . dir).
@@ -186,7 +194,7 @@ __device__ inline Force social_force(double dx, double dy, double ux, double uy)
   // 0 up to the last-bit noise of its own libm (which then decides sign(theta)). Take exactly 0.
   const double cross = ix * ey - iy * ex, dot = ix * ex + iy * ey;
   double phi;
-  if (lux == 0.0 && luy == 0.0) {
+  if (ux == 0.0 && uy == 0.0) {
     phi = 0.0;
   } else if (fabs(cross) >= 1e-6) {
     phi = atan2(cross, dot);
@@ -517,6 +525,8 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   for (int i = 0; i < kSoc; ++i) soc[i] = 0.0;
   double pbest = 1.7976931348623157e308, pdx = 0.0, pdy = 0.0;
   if (c.has_people) {
+    double su[4] = {0.0, 0.0, 0.0, 0.0};  // sums over valid agents of dF/du: (fx,ux) (fy,ux) (fx,uy) (fy,uy)
+    double qh[4] = {0.0, 0.0, 0.0, 0.0};  // sums over regular pairs of F . dF/d(x, y, ux, uy)
     const double* ag = c.ag;
     const unsigned long long* vmask = reinterpret_cast<const unsigned long long*>(c.lds + c.L.valid);
     const int TN = T * N;
@@ -537,18 +547,20 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         if (d2 < pbest) { pbest = d2; pdx = dx; pdy = dy; }  // proxemics: first minimum wins (std::min on duals)
         // force on the robot from this agent (:125): diff = robot - agent, u = robotVel - agentVel
         const Force F = social_force(dx, dy, rvx - awx, rvy - awy);
-        const double dFx_dth = vb * (-s1 * F.dfx_dux + c1 * F.dfx_duy), dFy_dth = vb * (-s1 * F.dfy_dux + c1 * F.dfy_duy);
-        const double dFx_dv = c1 * F.dfx_dux + s1 * F.dfx_duy, dFy_dv = c1 * F.dfy_dux + s1 * F.dfy_duy;
         soc[0] += F.fx; soc[1] += F.fy;
         soc[2] += F.dfx_dx; soc[3] += F.dfy_dx; soc[4] += F.dfx_dy; soc[5] += F.dfy_dy;
-        soc[6] += dFx_dth; soc[7] += dFy_dth; soc[8] += dFx_dv; soc[9] += dFy_dv;
+        // derivatives with respect to the robot's (theta, v) are one rotation of the u-derivatives that is the same
+        // for every agent of this step (u = v (cos theta, sin theta) - agentVel): sum the u-derivatives, rotate once
+        // after the loop
+        su[0] += F.dfx_dux; su[1] += F.dfy_dux; su[2] += F.dfx_duy; su[3] += F.dfy_duy;
         if (!degenerate) {
-          // force on the agent from the robot (:137-143) is exactly -F for a non-degenerate pair
-          soc[10] += F.fx * F.fx + F.fy * F.fy;
-          soc[11] += 2.0 * (F.fx * F.dfx_dx + F.fy * F.dfy_dx);
-          soc[12] += 2.0 * (F.fx * F.dfx_dy + F.fy * F.dfy_dy);
-          soc[13] += 2.0 * (F.fx * dFx_dth + F.fy * dFy_dth);
-          soc[14] += 2.0 * (F.fx * dFx_dv + F.fy * dFy_dv);
+          // force on the agent from the robot (:137-143) is exactly -F for a non-degenerate pair: |F|^2 and the
+          // halves of its derivatives (doubled, and the u-parts rotated, after the loop)
+          soc[10] = fma(F.fx, F.fx, fma(F.fy, F.fy, soc[10]));
+          qh[0] = fma(F.fx, F.dfx_dx, fma(F.fy, F.dfy_dx, qh[0]));
+          qh[1] = fma(F.fx, F.dfx_dy, fma(F.fy, F.dfy_dy, qh[1]));
+          qh[2] = fma(F.fx, F.dfx_dux, fma(F.fy, F.dfy_dux, qh[2]));
+          qh[3] = fma(F.fx, F.dfx_duy, fma(F.fy, F.dfy_duy, qh[3]));
         }
       }
       if (!valid || degenerate) {
@@ -564,6 +576,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         soc[14] += 2.0 * (G.fx * gx_v + G.fy * gy_v);
       }
     }
+    soc[6] = vb * (-s1 * su[0] + c1 * su[2]); soc[7] = vb * (-s1 * su[1] + c1 * su[3]);  // d(sum F)/d theta
+    soc[8] = c1 * su[0] + s1 * su[2]; soc[9] = c1 * su[1] + s1 * su[3];                  // d(sum F)/d v
+    soc[11] += 2.0 * qh[0];
+    soc[12] += 2.0 * qh[1];
+    soc[13] += 2.0 * (vb * (-s1 * qh[2] + c1 * qh[3]));
+    soc[14] += 2.0 * (c1 * qh[2] + s1 * qh[3]);
   }
 
   SMPC_STAMP(c, 3);
