@@ -482,7 +482,9 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     for (int b = 0; b < NB; ++b) {
       const int end = (b == NB - 1) ? T : (b + 1) * bl;
       const double wdt = xp[2 * b + 1] * dt;
-      for (; j < end; ++j) th += (j < sl) ? wdt : 0.0;
+      // (j < sl ? 1 : 0) * wdt added with one fma: the product with 1.0 is exact, so the sum is the reference's, and the
+      // 0 / 1 mask costs one 32-bit select (only the high words of 0.0 and 1.0 differ) instead of a 64-bit one
+      for (; j < end; ++j) th = fma((j < sl) ? 1.0 : 0.0, wdt, th);
     }
   }
   {
@@ -511,9 +513,9 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
       for (int u = 0; u < 8; ++u) { ax[u] = px_[j + u]; ay[u] = py_[j + u]; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const bool on = (j + u) <= sl; X += on ? ax[u] : 0.0; Y += on ? ay[u] : 0.0; }
+      for (int u = 0; u < 8; ++u) { const double m = ((j + u) <= sl) ? 1.0 : 0.0; X = fma(m, ax[u], X); Y = fma(m, ay[u], Y); }
     }
-    for (; j < T; ++j) { const bool on = j <= sl; X += on ? px_[j] : 0.0; Y += on ? py_[j] : 0.0; }
+    for (; j < T; ++j) { const double m = (j <= sl) ? 1.0 : 0.0; X = fma(m, px_[j], X); Y = fma(m, py_[j], Y); }
   }
   const int t1 = min(sl + 1, T);
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
@@ -602,21 +604,21 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const bool on = (j + u) <= sl;
-          const double kk = (double)(j + u - start);
-          aC += on ? cj[u] : 0.0;
-          aS += on ? sj[u] : 0.0;
-          aJC = on ? fma(kk, cj[u], aJC) : aJC;
-          aJS = on ? fma(kk, sj[u], aJS) : aJS;
+          const double m = on ? 1.0 : 0.0, mk = on ? (double)(j + u - start) : 0.0;  // masks: one 32-bit select each
+          aC = fma(m, cj[u], aC);
+          aS = fma(m, sj[u], aS);
+          aJC = fma(mk, cj[u], aJC);
+          aJS = fma(mk, sj[u], aJS);
         }
       }
       for (; j < end; ++j) {
         const double cj = cs_[j], sj = sn_[j];
         const bool on = j <= sl;
-        const double kk = (double)(j - start);
-        aC += on ? cj : 0.0;
-        aS += on ? sj : 0.0;
-        aJC = on ? fma(kk, cj, aJC) : aJC;
-        aJS = on ? fma(kk, sj, aJS) : aJS;
+        const double m = on ? 1.0 : 0.0, mk = on ? (double)(j - start) : 0.0;
+        aC = fma(m, cj, aC);
+        aS = fma(m, sj, aS);
+        aJC = fma(mk, cj, aJC);
+        aJS = fma(mk, sj, aJS);
       }
       Sxv[b] = dt * aC;
       Syv[b] = dt * aS;
