@@ -302,13 +302,18 @@ __device__ inline void bicubic(const uint8_t* __restrict__ map, int size_x, int 
 #define SMPC_STAMP(ctx, phase) do { } while (0)
 #endif
 
+// Kernel parameters are read through the kernel-argument segment (constant address space) instead of being held in
+// SGPRs for the whole kernel: the ~90 scalars of KParams otherwise overflow the SGPR file and come back as
+// v_readlane / v_writelane spill traffic on the VALU (1.4 k such instructions in the solve kernel before).
+typedef const KParams __attribute__((address_space(4))) * KParamsK;
+
 struct Ctx {
 #ifdef SMPC_STAMPS
   unsigned long long t_last;
   unsigned long long acc[8];
   unsigned long long acc2[4];
 #endif
-  const KParams* kp;
+  KParamsK kp;  // the launch parameters, read where they lie in the kernel-argument segment
   int scene;   // scene index of this slot
   int sl;      // lane within the slot = horizon step owned by this lane (per-lane)
   int slot;
@@ -356,7 +361,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // masked off).
 template <int W>
 __device__ inline void load_scene(Ctx& c, int scene) {
-  const KParams& k = *c.kp;
+  const auto& k = *c.kp;
   const int T = k.T, N = k.N, sl = c.sl;
   const size_t s = scene;
   c.scene = scene;
@@ -463,7 +468,7 @@ __device__ inline void load_scene(Ctx& c, int scene) {
 template <int NB, int W>
 __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J) {
   constexpr int P = 2 * NB;
-  const KParams& k = *c.kp;
+  const auto& k = *c.kp;
   const int T = k.T, N = k.N, CH = k.CH, bl = k.bl, sl = c.sl;
   const double dt = k.dt;
   double* cs_ = c.lds + c.L.cs;
@@ -640,7 +645,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   constexpr bool kMfma = use_mfma(P, W);
   constexpr int kCols = tile_cols(W);
   constexpr int Q = P + 1;
-  const smpc_params& w = k.prm;
+  const auto& w = k.prm;
   const bool lane_live = sl < T;
   const bool people = c.has_people;
   const int rows_per_step = people ? 8 : 5;

@@ -502,7 +502,8 @@ struct LmRegs {  // slot-uniform integers / flags kept in registers
 #define SMPC_SOLVE_MIN_WAVES 2   // waves per SIMD the solve kernel's register allocation must allow
 #endif
 template <int NB, int W>
-__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(const KParams k) {
+__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(const KParams) {
+  const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
   extern __shared__ double lds_all[];
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
   c.ag = k.ws_ag + ((size_t)blockIdx.x * S + slot) * 4 * k.T * (k.N > 0 ? k.N : 1);
-  const smpc_params& prm = k.prm;
+  const auto& prm = k.prm;
   const int T = k.T;
   double* Hs = c.lds + c.L.lm;   // [P*P reserved] scaled J^T J at the current point, packed lower triangle tri(i, j)
   double* gs = Hs + P * P;       // [P] scaled gradient
@@ -837,7 +838,8 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 #define SMPC_EVAL_MIN_WAVES 1
 #endif
 template <int NB, int W>
-__global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(const KParams k) {
+__global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(const KParams) {
+  const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
   extern __shared__ double lds_all[];
