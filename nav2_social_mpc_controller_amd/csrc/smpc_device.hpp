@@ -50,7 +50,7 @@ struct KParams {
   double* o_initial_cost;
   double* o_final_cost;
   int* queue;  // scene work queue (one int, zeroed before every solve launch)
-  double* ws_ag;  // solve kernel: staged people blocks, [grid * slots][4][N][T] (L2-resident workspace)
+  double* ws_ag;  // solve kernel: staged people blocks, [grid * slots][N][T][4] (L2-resident workspace)
   unsigned long long* stamps;  // diagnostic builds only (SMPC_STAMPS): per-wave cycle sums per phase, [grid][8]
   // eval (K1) inputs / outputs
   const double* e_x;
@@ -63,7 +63,7 @@ struct KParams {
 
 // LDS carve-up (in doubles) of ONE slot.
 struct LdsLayout {
-  int ag;       // [4][N][T]  staged people block (px, py, vx, vy) — stand-alone K1 only; the solve kernel keeps it
+  int ag;       // [N][T][4]  staged people block (px, py, vx, vy) — stand-alone K1 only; the solve kernel keeps it
                 //            in a global workspace instead (LDS footprint of a persistent wave stays near 10 KB)
   int valid;    // [T]        bit a set = agent a valid at step t (64-bit words)
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
@@ -92,7 +92,7 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, bool with_
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
   L.scratch = o; if (with_lm) o += 96;  // generic line-search interpolation fallback
-  L.total = (o + 1) & ~1;
+  L.total = (o + 3) & ~3;  // 32-byte multiple: the staged people records are read as 4-double vectors
   return L;
 }
 
@@ -320,7 +320,7 @@ struct Ctx {
   bool has_people;
   const uint8_t* map;
   double* lds;       // this slot's LDS block (scene constants, cos/sin block, LM state live here)
-  double* ag;        // staged people block [4][N][T] of this slot (LDS in K1, global workspace in the solve kernel)
+  double* ag;        // staged people block [N][T][4] of this slot (LDS in K1, global workspace in the solve kernel)
   double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
   LdsLayout L;
 };
@@ -356,7 +356,8 @@ struct GramView {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// Load the slot's scene constants, stage its people block (px, py, vx, vy per (agent, step)) into c.ag and the valid
+// Load the slot's scene constants, stage its people block (one 32-byte record px, py, vx, vy per (agent, step), record
+// index a * T + t) into c.ag and the valid
 // mask per step into LDS, compute the agent-angle tags. Executed by all W lanes of the slot (other slots may be
 // masked off).
 template <int W>
@@ -405,10 +406,8 @@ __device__ inline void load_scene(Ctx& c, int scene) {
           double sn, cs;
           sincos(gyaw[u], &sn, &cs);
           const int q = a * T + t;
-          ag[q] = gx[u];
-          ag[TN + q] = gy[u];
-          ag[2 * TN + q] = glv[u] * cs;  // aVel, social_work:187-188
-          ag[3 * TN + q] = glv[u] * sn;
+          v4d rec = {gx[u], gy[u], glv[u] * cs, glv[u] * sn};  // aVel, social_work:187-188
+          reinterpret_cast<v4d*>(ag)[q] = rec;  // one 32-byte record (px, py, vx, vy) per (agent, step)
         }
       }
     }
@@ -541,11 +540,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
     // software prefetch of the next agent's entry of the staged block (L2-resident workspace in the solve kernel,
     // LDS in the stand-alone K1 kernel)
-    double npx = ag[tl], npy = ag[TN + tl], nwx = ag[2 * TN + tl], nwy = ag[3 * TN + tl];
+    const v4d* agr = reinterpret_cast<const v4d*>(ag) + tl;  // records of this lane's step: agent a at agr[a * T]
+    v4d nrec = agr[0];
 #pragma unroll 2  // two agents per trip: measured +4% on the fused solve kernel (more independent work per wave)
     for (int a = 0; a < N; ++a) {
-      double apx = npx, apy = npy, awx = nwx, awy = nwy;
-      if (a + 1 < N) { const int q = (a + 1) * T + tl; npx = ag[q]; npy = ag[TN + q]; nwx = ag[2 * TN + q]; nwy = ag[3 * TN + q]; }
+      const double apx = nrec[0], apy = nrec[1], awx = nrec[2], awy = nrec[3];
+      if (a + 1 < N) nrec = agr[(a + 1) * T];
       const bool valid = (vm >> a) & 1ull;
       const double dx = X - apx, dy = Y - apy;
       const double d2 = dx * dx + dy * dy;

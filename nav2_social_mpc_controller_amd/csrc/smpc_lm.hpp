@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
-  extern __shared__ double lds_all[];
+  extern __shared__ __attribute__((aligned(32))) double lds_all[];
   const int lane = threadIdx.x & 63;
   const int slot = lane / W;
   Ctx c;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
-  extern __shared__ double lds_all[];
+  extern __shared__ __attribute__((aligned(32))) double lds_all[];
   const int lane = threadIdx.x & 63;
   const int slot = lane / W;
   Ctx c;
