@@ -55,6 +55,27 @@ def test_struct_layouts_match_the_c_header(tmp_path):
                     _abi.SmpcSceneBatch.costmap_origin.offset, _abi.SmpcSceneBatch.resolution.offset]
 
 
+def test_next_row_struct_layouts_match_the_c_header(tmp_path):
+    """ctypes mirrors of the SURVEY §8(f) structs: sizes and a late field's offset each."""
+    probes = [("smpc_projection_batch", _abi.SmpcProjectionBatch, "od_origin"),
+              ("smpc_people_batch", _abi.SmpcPeopleBatch, "resolution"),
+              ("smpc_memory_batch", _abi.SmpcMemoryBatch, "valid"),
+              ("smpc_format_batch", _abi.SmpcFormatBatch, "memory"),
+              ("smpc_format_out", _abi.SmpcFormatOut, "goal_yaw"),
+              ("smpc_trajectorize_batch", _abi.SmpcTrajectorizeBatch, "robot_pose"),
+              ("smpc_trajectorize_out", _abi.SmpcTrajectorizeOut, "error")]
+    body = "".join(f'printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {f}));\n' for c, _, f in probes)
+    prog = tmp_path / "layout2.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "smpc.h"\nint main(void){\n' + body + 'return 0;}\n')
+    exe = tmp_path / "layout2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)], text=True).splitlines()
+    for (cname, py, field), line in zip(probes, lines):
+        size, off = (int(v) for v in line.split())
+        assert size == C.sizeof(py), cname
+        assert off == getattr(py, field).offset, (cname, field)
+
+
 def test_params_default_matches_reference_code_defaults():
     lib = S.load_library()
     p = _abi.SmpcParams()
