@@ -304,6 +304,17 @@ typedef struct smpc_trajectorize_out {
 
 int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* in, smpc_trajectorize_out* out);
 
+/* The command SocialMPCController::computeVelocityCommands returns (src/social_mpc_controller.cpp:176-256; SURVEY §8 row
+ * f4) for B robots: cmds[0] of a usable solve (:250-256), the trajectorizer's first command when the optimisation was
+ * not usable (:241-245) or — a limit of the fixed-T batch — when the trajectorized path was shorter than T + 1 poses,
+ * and (0.1, 0) when trajectorize returned false (:180-189). source [B]: 0 optimised, 1 trajectorizer command,
+ * 2 the 0.1 m/s fallback. */
+int smpc_select_command_batch(smpc_handle* h, int32_t B, int32_t T, int32_t traj_rows, int32_t on_device,
+                              const int32_t* traj_n_poses /* [B]; NULL: every path is complete */,
+                              const double* traj_cmds /* [B][traj_rows][2] */, const int32_t* status /* [B] */,
+                              const double* cmds /* [B][T+1][2] */, double* cmd_vel /* [B][2] */,
+                              int32_t* source /* [B]; may be NULL */);
+
 /* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
  * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */
 double smpc_last_kernel_ms(smpc_handle* h);

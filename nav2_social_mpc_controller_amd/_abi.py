@@ -212,6 +212,7 @@ EXPORTED_SYMBOLS = [
     "smpc_format_to_optimize_batch",
     "smpc_memory_store_batch",
     "smpc_trajectorize_path_batch",
+    "smpc_select_command_batch",
     "smpc_last_kernel_ms",
     "smpc_last_error",
     "smpc_abi_version",

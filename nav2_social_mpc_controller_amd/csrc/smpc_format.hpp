@@ -171,4 +171,32 @@ __global__ __launch_bounds__(256) void smpc_memory_store_kernel(const StoreParam
   if (gid - (long long)s * Tp == 0) p.valid[s] = 1;
 }
 
+struct SelectParams {
+  int B, T, rows;
+  const int32_t* traj_n;   // [B] or null
+  const double* traj_cmds; // [B][rows][2]
+  const int32_t* status;   // [B]
+  const double* cmds;      // [B][T+1][2]
+  double* cmd_vel;         // [B][2]
+  int32_t* source;         // [B] or null
+};
+
+// computeVelocityCommands' choice of the returned command (src/social_mpc_controller.cpp:180-189, 241-245, 250-256).
+__global__ __launch_bounds__(256) void smpc_select_command_kernel(const SelectParams p) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.B) return;
+  const int n = p.traj_n ? p.traj_n[s] : p.T + 1;
+  int src;
+  double v, w;
+  if (n <= 0) {  // trajectorize() returned false: "using fallback cmd_vel"
+    src = 2; v = 0.1; w = 0.0;
+  } else if (n < p.T + 1 || p.status[s] == 2 /* SMPC_FAILURE */) {  // cmds = init_cmds
+    src = 1; v = p.traj_cmds[(size_t)s * p.rows * 2]; w = p.traj_cmds[(size_t)s * p.rows * 2 + 1];
+  } else {
+    src = 0; v = p.cmds[(size_t)s * (p.T + 1) * 2]; w = p.cmds[(size_t)s * (p.T + 1) * 2 + 1];
+  }
+  p.cmd_vel[2 * s] = v; p.cmd_vel[2 * s + 1] = w;
+  if (p.source) p.source[s] = src;
+}
+
 }  // namespace smpc

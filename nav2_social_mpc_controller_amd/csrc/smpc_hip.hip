@@ -623,6 +623,41 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
   return SMPC_OK;
 }
 
+int smpc_select_command_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t traj_rows, int32_t on_device, const int32_t* traj_n_poses,
+                              const double* traj_cmds, const int32_t* status, const double* cmds, double* cmd_vel, int32_t* source) {
+  if (!h || !traj_cmds || !status || !cmds || !cmd_vel) { set_error("null handle / array"); return SMPC_ERR_INVALID_ARG; }
+  if (B_ < 0 || T < 1 || traj_rows < 1) { set_error("bad B / T / traj_rows"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t B = B_;
+  smpc::SelectParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = B_; p.T = T; p.rows = traj_rows;
+  Staging st(h);
+  if (on_device) {
+    p.traj_n = traj_n_poses; p.traj_cmds = traj_cmds; p.status = status; p.cmds = cmds; p.cmd_vel = cmd_vel; p.source = source;
+  } else {
+    SMPC_TRY(st.up(traj_n_poses, B, &p.traj_n, h->stream));
+    SMPC_TRY(st.up(traj_cmds, B * (size_t)traj_rows * 2, &p.traj_cmds, h->stream));
+    SMPC_TRY(st.up(status, B, &p.status, h->stream));
+    SMPC_TRY(st.up(cmds, B * ((size_t)T + 1) * 2, &p.cmds, h->stream));
+    SMPC_TRY(st.out(cmd_vel, B * 2, &p.cmd_vel));
+    SMPC_TRY(st.out(source, B, &p.source));
+  }
+  if (B > 0) {
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_select_command_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!on_device) {
+    SMPC_TRY(down(cmd_vel, p.cmd_vel, B * 2, h->stream));
+    SMPC_TRY(down(source, p.source, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
 int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* params, smpc_eval_batch_out* out) {
   Dims d;
   SMPC_TRY(validate(h, sb, &d));

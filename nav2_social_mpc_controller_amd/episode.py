@@ -124,6 +124,8 @@ class BatchEpisode:
         self.people_proj = torch.zeros((B, T + 1, 6, N), **f64)
         self.proj_error = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.rb, self.res = self.solver.alloc_results(B, T, self.dev)
+        self.cmd_vel = torch.zeros((B, 2), **f64)                      # the command returned to the robot this tick
+        self.cmd_source = torch.zeros(B, dtype=torch.int32, device=self.dev)  # 0 optimised, 1 trajectorizer, 2 creep
         self.ticks = 0
         self.parked = None  # plan mode: scenes parked in the last tick (bool tensor)
 
@@ -242,21 +244,18 @@ class BatchEpisode:
                        goal_yaw=self.goal_yaw.cpu().numpy().copy(), people_proj=self.people_proj.cpu().numpy().copy(),
                        proj_error=self.proj_error.cpu().numpy().copy(),
                        result={k: v.cpu().numpy().copy() for k, v in self.res.items()}, memory_after=self._memory_host())
-        # 5. the world moves one period with the command computeVelocityCommands returns: cmds[0] of a usable solve (the
-        #    robot lands on the first optimised pose), the trajectorizer's first command otherwise (:241-245), 0.1 m/s
-        #    straight ahead when trajectorize() returned false (:180-189)
-        ok = (self.res["status"] != 2)
+        # 5. the command computeVelocityCommands returns (fallbacks included), then the world moves one period with it:
+        #    a usable solve lands the robot on the first optimised pose, a fallback command is integrated with the
+        #    trajectorizer's own motion model (x, y with the old heading, then the heading)
+        s.select_command_device(B, T, self.rows, self.traj_n.data_ptr() if self.plan is not None else 0,
+                                self.plan_cmds.data_ptr(), self.res["status"].data_ptr(), self.res["cmds"].data_ptr(),
+                                self.cmd_vel.data_ptr(), self.cmd_source.data_ptr())
         dt = prm.dt
-        fb_pose, fb_speed = self.plan_path[:, 1, :], self.plan_cmds[:, 0, :]
-        if self.plan is not None:
-            none = (self.traj_n == 0)[:, None]
-            creep = torch.stack([self.pose[:, 0] + 0.1 * dt * torch.cos(self.pose[:, 2]),
-                                 self.pose[:, 1] + 0.1 * dt * torch.sin(self.pose[:, 2]), self.pose[:, 2]], dim=1)
-            slow = torch.zeros_like(self.speed)
-            slow[:, 0] = 0.1
-            fb_pose, fb_speed = torch.where(none, creep, fb_pose), torch.where(none, slow, fb_speed)
-        self.pose = torch.where(ok[:, None], self.res["path"][:, 0, :], fb_pose).contiguous()
-        self.speed = torch.where(ok[:, None], self.res["cmds"][:, 0, :], fb_speed).contiguous()
+        v, w, th = self.cmd_vel[:, 0], self.cmd_vel[:, 1], self.pose[:, 2]
+        moved = torch.stack([self.pose[:, 0] + v * torch.cos(th) * dt, self.pose[:, 1] + v * torch.sin(th) * dt, th + w * dt], dim=1)
+        optimised = (self.cmd_source == 0)[:, None]
+        self.pose = torch.where(optimised, self.res["path"][:, 0, :], moved).contiguous()
+        self.speed = self.cmd_vel.clone()
         self.persons[:, :, 0] += self.persons[:, :, 2] * dt
         self.persons[:, :, 1] += self.persons[:, :, 3] * dt
         self.ticks += 1

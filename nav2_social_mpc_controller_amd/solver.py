@@ -69,6 +69,8 @@ def load_library():
     lib.smpc_memory_store_batch.restype = C.c_int
     lib.smpc_trajectorize_path_batch.argtypes = [C.c_void_p, C.POINTER(SmpcTrajectorizeBatch), C.POINTER(SmpcTrajectorizeOut)]
     lib.smpc_trajectorize_path_batch.restype = C.c_int
+    lib.smpc_select_command_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    lib.smpc_select_command_batch.restype = C.c_int
     lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
     lib.smpc_last_kernel_ms.restype = C.c_double
     if lib.smpc_abi_version() != _abi.SMPC_ABI_VERSION:
@@ -223,6 +225,26 @@ class BatchSolver:
         _check(self.lib, self.lib.smpc_people_to_status_batch(self._h, C.byref(pb), out.ctypes.data, has.ctypes.data),
                "smpc_people_to_status_batch")
         return out, has
+
+    def select_command(self, traj_n_poses, traj_cmds: np.ndarray, status: np.ndarray, cmds: np.ndarray):
+        """The command computeVelocityCommands returns for B robots (fallbacks included): traj_cmds [B,rows,2],
+        status [B], cmds [B,T+1,2], traj_n_poses [B] or None. Returns (cmd_vel [B,2], source [B])."""
+        traj_cmds = np.ascontiguousarray(traj_cmds, np.float64)
+        status = np.ascontiguousarray(status, np.int32)
+        cmds = np.ascontiguousarray(cmds, np.float64)
+        B, rows, _ = traj_cmds.shape
+        T = cmds.shape[1] - 1
+        n = None if traj_n_poses is None else np.ascontiguousarray(traj_n_poses, np.int32)
+        out, src = np.zeros((B, 2)), np.zeros(B, np.int32)
+        _check(self.lib, self.lib.smpc_select_command_batch(self._h, B, T, rows, 0, None if n is None else n.ctypes.data,
+                                                            traj_cmds.ctypes.data, status.ctypes.data, cmds.ctypes.data,
+                                                            out.ctypes.data, src.ctypes.data), "smpc_select_command_batch")
+        return out, src
+
+    def select_command_device(self, B, T, rows, traj_n_ptr, traj_cmds_ptr, status_ptr, cmds_ptr, cmd_vel_ptr, source_ptr):
+        _check(self.lib, self.lib.smpc_select_command_batch(self._h, B, T, rows, 1, C.c_void_p(traj_n_ptr), C.c_void_p(traj_cmds_ptr),
+                                                            C.c_void_p(status_ptr), C.c_void_p(cmds_ptr), C.c_void_p(cmd_vel_ptr),
+                                                            C.c_void_p(source_ptr)), "smpc_select_command_batch")
 
     # -- warm start / input formatting (SURVEY §8 row f2): format_to_optimize + TrajectoryMemory for B scenes -----
     def format_to_optimize(self, path: np.ndarray, cmds: np.ndarray, speed: np.ndarray, memory: dict,

@@ -27,6 +27,8 @@ def test_episode_ticks_match_cpu_chain(oracle):
     n_checked = 0
     for tick in range(3):
         r = ep.tick(record=True)
+        # the command handed to the robot: cmds[0] of the solve (no fallback is active in these scenes)
+        assert (ep.cmd_source.cpu().numpy() == 0).all() and np.array_equal(ep.cmd_vel.cpu().numpy(), r.result["cmds"][:, 0])
         # --- f2: people_to_status (no field-of-view filter in this episode)
         st, has = pyref_format.people_to_status(r.persons, r.person_count, N)
         assert np.max(np.abs(r.init_people - st)) <= 1e-14 and np.array_equal(r.has_people, has)
@@ -90,6 +92,8 @@ def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
     seen = 0
     for tick in range(3):
         r = ep.tick(record=True)
+        # the command handed to the robot: cmds[0] of the solve (no fallback is active in these scenes)
+        assert (ep.cmd_source.cpu().numpy() == 0).all() and np.array_equal(ep.cmd_vel.cpu().numpy(), r.result["cmds"][:, 0])
         assert (r.traj_n_poses == tp.max_steps + 1).all()
         # f4 / f2: field-of-view filter + people_to_status from the world people and the pose the tick started from
         for s in range(B):

@@ -216,3 +216,21 @@ def test_gpu_fov_filter_matches_pyref(fov):
     exp, ehas, kept = pyref_fov_status(pose, people, count, origin, sx, sy, res, fov, 3)
     assert np.array_equal(has, ehas) and np.max(np.abs(got - exp)) <= 1e-14
     assert (kept == 0).any() and (kept > 3).any()
+
+
+@pytest.mark.gpu
+def test_gpu_select_command_applies_the_reference_fallbacks():
+    """computeVelocityCommands' returned command: optimised cmds[0], else the trajectorizer's first command
+    (src/social_mpc_controller.cpp:241-245), else 0.1 m/s straight (:180-189)."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    rng = np.random.default_rng(12)
+    B, T, rows = 300, 28, 31
+    traj_cmds, cmds = rng.normal(size=(B, rows, 2)), rng.normal(size=(B, T + 1, 2))
+    status = rng.integers(0, 3, size=B).astype(np.int32)
+    n = rng.choice([0, 5, T + 1, rows], size=B).astype(np.int32)
+    got, src = BatchSolver(OptimizerParams.readme()).select_command(n, traj_cmds, status, cmds)
+    want_src = np.where(n <= 0, 2, np.where((n < T + 1) | (status == 2), 1, 0))
+    want = np.where((want_src == 2)[:, None], np.array([0.1, 0.0]), np.where((want_src == 1)[:, None], traj_cmds[:, 0], cmds[:, 0]))
+    assert np.array_equal(src, want_src) and np.array_equal(got, want)
+    assert set(want_src.tolist()) == {0, 1, 2}
