@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 2
+#define SMPC_ABI_VERSION 3
 #define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20 */
 
 /* linear_solver_type: mirrors OptimizerParams::solver_types (optimizer.hpp:71-77). */
@@ -121,7 +121,15 @@ typedef struct smpc_scene_batch {
   int32_t size_x, size_y;       /* getSizeInCellsX/Y */
   const double* costmap_origin; /* [B][2] or [1][2] when shared: getOriginX/Y */
   double resolution;            /* getResolution */
+
+  /* Optional (both or neither; same memory space): the people block in the form the sweep reads, as written by
+   * smpc_stage_people_batch for the same pose0 / people / has_people. When NULL the library stages `people` itself
+   * (one extra kernel per call). When given, `people` is not read and may be NULL. */
+  const double* people_records; /* [B][N][T][4] px, py, lv cos(yaw), lv sin(yaw) of people_proj[t+1][a] */
+  const double* people_aux;     /* [B][T][2]    bits of the valid-agent mask (t != -1), agent-angle target or SMPC_NO_TARGET */
 } smpc_scene_batch;
+
+#define SMPC_NO_TARGET 1e300 /* people_aux: AgentAngleCost is inactive at this step */
 
 typedef struct smpc_result_batch {
   /* Any pointer may be NULL (that output is skipped). Same memory space as the scene batch. */
@@ -191,6 +199,13 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* scenes, smpc_result
 /* Evaluate residuals / Jacobian at `params` ([B][P], same memory space) — kernel K1 alone. */
 int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* scenes, const double* params,
                     smpc_eval_batch_out* out);
+
+/* Stage the people block of `scenes` (reads B, T, N, on_device, pose0, people, has_people) into the form the sweep
+ * reads: records [B][N][T][4] and aux [B][T][2] (layouts: smpc_scene_batch.people_records / people_aux). Everything the
+ * critics need from people_proj that does not depend on the optimised parameters is computed here, once per people
+ * block: the agents' velocity vectors (social_work_cost_function.hpp:187-188), the validity test (:175) and the
+ * steering target of AgentAngleCost (agent_angle_cost_function.hpp:130-190). */
+int smpc_stage_people_batch(smpc_handle* h, const smpc_scene_batch* scenes, double* records, double* aux);
 
 /* Roll the people forward with the Social Force Model: people_proj [B][T+1][6][N] (the layout smpc_scene_batch.people
  * expects; entry 0 = init_people, valid agents compacted to the front, the rest padded with t = -1 like the reference),
@@ -314,6 +329,12 @@ int smpc_select_command_batch(smpc_handle* h, int32_t B, int32_t T, int32_t traj
                               const double* traj_cmds /* [B][traj_rows][2] */, const int32_t* status /* [B] */,
                               const double* cmds /* [B][T+1][2] */, double* cmd_vel /* [B][2] */,
                               int32_t* source /* [B]; may be NULL */);
+
+/* Diagnostic: evaluates the elementary functions the sweep uses (csrc/smpc_math.hpp: table-driven exp / atan2 /
+ * sincos, refined reciprocal / rsqrt, and the raw hardware estimates behind them) on n host-side arguments, so that
+ * tests can check them on the device against libm. fn: 0 exp(a) | 1 atan2(a, b) | 2 sin(a) -> out0, cos(a) -> out1 |
+ * 3 1/sqrt(a) | 4 a / b | 5 raw v_rcp_f64(a) | 6 raw v_rsq_f64(a). out1 may be NULL unless fn == 2. */
+int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1);
 
 /* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
  * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */

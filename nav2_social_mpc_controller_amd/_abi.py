@@ -6,7 +6,7 @@ Struct layouts must stay in lock-step with include/smpc.h (checked by tests/test
 """
 import ctypes as C
 
-SMPC_ABI_VERSION = 2
+SMPC_ABI_VERSION = 3
 SMPC_MAX_BLOCKS = 10
 
 # enum smpc_linear_solver (mirrors OptimizerParams::solver_types, reference optimizer.hpp:71-77)
@@ -74,6 +74,8 @@ class SmpcSceneBatch(C.Structure):
         ("size_y", C.c_int32),
         ("costmap_origin", C.c_void_p),
         ("resolution", C.c_double),
+        ("people_records", C.c_void_p),
+        ("people_aux", C.c_void_p),
     ]
 
 
@@ -213,6 +215,8 @@ EXPORTED_SYMBOLS = [
     "smpc_memory_store_batch",
     "smpc_trajectorize_path_batch",
     "smpc_select_command_batch",
+    "smpc_math_probe",
+    "smpc_stage_people_batch",
     "smpc_last_kernel_ms",
     "smpc_last_error",
     "smpc_abi_version",

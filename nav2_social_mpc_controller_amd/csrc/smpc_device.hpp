@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "../../include/smpc.h"
+#include "smpc_math.hpp"
 
 namespace smpc {
 
@@ -50,7 +51,11 @@ struct KParams {
   double* o_initial_cost;
   double* o_final_cost;
   int* queue;  // scene work queue (one int, zeroed before every solve launch)
-  double* ws_ag;  // solve kernel: staged people blocks, [grid * slots][N][T][4] (L2-resident workspace)
+  // staged people block (smpc_stage_people_batch / the library's own staging pass): what the sweep reads
+  const double* people_rec;  // [B][N][T][4]  px, py, vx, vy of people_proj[t + 1][a]
+  const double* people_aux;  // [B][T][2]     bit mask of valid agents (u64 bits), agent-angle target (kNoTarget: none)
+  double* stage_rec;         // staging kernel outputs (same layouts)
+  double* stage_aux;
   unsigned long long* stamps;  // diagnostic builds only (SMPC_STAMPS): per-wave cycle sums per phase, [grid][8]
   // eval (K1) inputs / outputs
   const double* e_x;
@@ -59,12 +64,13 @@ struct KParams {
   double* e_cost;
   double* e_gradient;
   int e_M;  // row stride of the eval outputs (M with people)
+  MathTab mt;  // polynomial coefficients of smpc_math.hpp, read through scalar loads
 };
 
 // LDS carve-up (in doubles) of ONE slot.
 struct LdsLayout {
-  int ag;       // [N][T][4]  staged people block (px, py, vx, vy) — stand-alone K1 only; the solve kernel keeps it
-                //            in a global workspace instead (LDS footprint of a persistent wave stays near 10 KB)
+  int ag;       // [N][T][4]  staged people block (px, py, vx, vy) — staging kernel only; the sweep reads the staged
+                //            records from global memory (HBM once in K1, L2 on the later sweeps of a solve)
   int valid;    // [T]        bit a set = agent a valid at step t (64-bit words)
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
   int inc;      // [2][T]     per-step position increments of the current sweep
@@ -76,14 +82,15 @@ struct LdsLayout {
   int total;
 };
 
-// with_lm = true is the solve kernel: LM state in LDS, staged people block (px, py, vx, vy per agent and step,
-// re-read every sweep) in an L2-resident global workspace, which keeps the LDS footprint of a wave near 10 KB.
-// false is the stand-alone K1 kernel: a single sweep, people block staged in LDS (every people row is read from HBM
-// once, neighbouring lanes on neighbouring agents).
-__host__ __device__ inline LdsLayout make_layout(int T, int N, int P, bool with_lm) {
+enum LayoutKind { kLayoutEval = 0, kLayoutSolve = 1, kLayoutStage = 2 };
+
+// kLayoutSolve: LM state in LDS. kLayoutEval: the stand-alone K1 kernel, a single sweep. kLayoutStage: the staging
+// kernel, people block in LDS on its way to the staged records.
+__host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) {
   LdsLayout L;
+  const bool with_lm = kind == kLayoutSolve;
   int o = 0;
-  L.ag = o; if (!with_lm) o += 4 * T * (N > 0 ? N : 1);
+  L.ag = o; if (kind == kLayoutStage) o += 4 * T * (N > 0 ? N : 1);
   L.valid = o; o += T;
   L.cs = o; o += 2 * (T + 1);
   L.inc = o; o += 2 * T;
@@ -92,7 +99,7 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, bool with_
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
   L.scratch = o; if (with_lm) o += 96;  // generic line-search interpolation fallback
-  L.total = (o + 3) & ~3;  // 32-byte multiple: the staged people records are read as 4-double vectors
+  L.total = (o + 3) & ~3;  // 32-byte multiple: records are moved as 4-double vectors
   return L;
 }
 
@@ -110,13 +117,6 @@ __host__ __device__ constexpr int tile_slot_stride(int W) { return W * tile_cols
 // doubles of wave-shared LDS behind the per-slot blocks: row tile + 16x16 result tile
 __host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
   return use_mfma(P, W) ? (kWave / W) * tile_slot_stride(W) + 256 : 0;
-}
-
-// Stand-alone K1: the MFMA row / result tiles are only used after the agent loop, when the staged people block of the
-// wave is dead — they overlay slot 0's people block when it is large enough (keeps a W = 32 wave at ~19 KB of LDS, 8
-// waves per CU instead of 6).
-__host__ __device__ constexpr bool k1_tiles_overlay_people(int T, int N, int P, int W) {
-  return wave_extra_doubles(P, W) > 0 && 4 * T * (N > 0 ? N : 1) >= wave_extra_doubles(P, W);
 }
 
 // The workgroup is ONE wavefront: LDS operations of a wave execute in program order, so cross-lane hand-offs through
@@ -161,6 +161,7 @@ struct Force {
   double fx, fy;
   double dfx_dx, dfy_dx, dfx_dy, dfy_dy;      // wrt diff
   double dfx_dux, dfy_dux, dfx_duy, dfy_duy;  // wrt u
+  bool special;  // pair_force() only: this pair needs social_force_general() (theta within 1e-6 of 0 or pi)
 };
 
 // 1/sqrt(x) for a normal positive x: hardware estimate + one cubic correction (what the library routine does, without
@@ -172,7 +173,7 @@ __device__ inline double fast_rsqrt(double x) {
   return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
-__device__ inline Force social_force(double dx, double dy, double ux, double uy) {
+__device__ inline Force social_force_general(double dx, double dy, double ux, double uy) {
   const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, nn = 2.0, k = 2.1;
   Force R;
   double d2 = dx * dx + dy * dy;
@@ -256,6 +257,74 @@ __device__ inline Force social_force(double dx, double dy, double ux, double uy)
   return R;
 }
 
+// The same force for a regular pair (|diff| >= 1e-6, the overwhelmingly common case), built for instruction count:
+// table-driven exp / atan2 (smpc_math.hpp), no selects for the coincident-pair clamp, no branches. Two rare shapes
+// are only flagged, for the caller to redo the step's agents with social_force_general(): a coincident pair (flagged
+// by the caller) and a pair whose theta is within 1e-6 of 0 or pi while the velocities differ (Force::special: next
+// to the discontinuity of sign(theta) the reference's own two-atan2 form decides, :198-200).
+// pair_force(-d, -u) == -pair_force(d, u) bit for bit (every intermediate flips sign or stays exactly), with equal
+// derivatives: the force on an agent from the robot needs no evaluation of its own.
+__device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux, double uy) {
+  const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, nn = 2.0, k = 2.1;
+  Force R;
+  const double d2 = fma(dx, dx, dy * dy);
+  const double inv_n = rsqrt_pos(d2);
+  const double n = d2 * inv_n;
+  const double ex = dx * inv_n, ey = dy * inv_n;  // diffDirection :185
+  const double ivx = fma(lambda, ux, ex), ivy = fma(lambda, uy, ey);  // :191-192
+  const double L2 = fma(ivx, ivx, ivy * ivy);
+  const double inv_L = rsqrt_pos(L2);
+  const double L = L2 * inv_L;  // :194
+  const double ix = ivx * inv_L, iy = ivy * inv_L;  // :195-196
+  const double cross = fma(ix, ey, -(iy * ex)), dot = fma(ix, ex, iy * ey);
+  const bool zero_u = (ux == 0.0) & (uy == 0.0);  // equal velocities: theta := 0 (parity)
+  double phi = atan2_dir(mt, cross, dot);
+  R.special = !zero_u & (fabs(cross) < 1e-6);
+  phi = zero_u ? 0.0 : phi;
+  const double Bq = gamma * L;  // :203
+  const double inv_B = inv_L * (1.0 / gamma);
+  const double a1 = nPrime * Bq * phi, a2 = nn * Bq * phi;
+  const double base = -n * inv_B;
+  const double E1 = exp_tab(mt, fma(-a1, a1, base));  // :205-207
+  const double E2 = exp_tab(mt, fma(-a2, a2, base));  // :212-215
+  const double fv = -E1;
+  const double fa = (phi > 0.0) ? -E2 : E2;  // -sign(theta) E2, sign = -1 at theta == 0 (:210)
+  R.fx = k * (fv * ix - fa * iy);  // :218-224, i_perp = (-iy, ix)
+  R.fy = k * (fv * iy + fa * ix);
+  // derivative: see social_force_general(); dfa = sgn E2 (...) = -fa (...)
+  const double nB2 = n * inv_B * inv_B;
+  const double anx = -inv_B * R.fx, any = -inv_B * R.fy;
+  const double twoB = 2.0 * Bq;
+  const double g1 = a1 * nPrime, g2 = a2 * nn;
+  double aax, aay;
+  {
+    const double dfv = E1 * (g1 * twoB);
+    const double dfa = -fa * (g2 * twoB);
+    aax = k * (dfv * ix - dfa * iy);
+    aay = k * (dfv * iy + dfa * ix);
+  }
+  auto column = [&](double dL, double kappa, double& ofx, double& ofy) {
+    const double dB = gamma * dL;
+    const double dbase = nB2 * dB;
+    const double common = 2.0 * fma(dB, phi, -(Bq * kappa));  // dphi = -kappa
+    const double dfv = fv * fma(-g1, common, dbase);
+    const double dfa = fa * fma(-g2, common, dbase);
+    const double ci = fma(-fa, kappa, dfv), cp = fma(fv, kappa, dfa);
+    ofx = k * (ci * ix - cp * iy);
+    ofy = k * (ci * iy + cp * ix);
+  };
+  double axx, axy, ayx, ayy;
+  column(ix, -iy * inv_L, axx, axy);
+  column(iy, ix * inv_L, ayx, ayy);
+  R.dfx_dux = lambda * axx; R.dfy_dux = lambda * axy;
+  R.dfx_duy = lambda * ayx; R.dfy_duy = lambda * ayy;
+  const double cx = aax - ey * axx + ex * ayx, cy = aay - ey * axy + ex * ayy;
+  const double da1 = -ey * inv_n, da2 = ex * inv_n;
+  R.dfx_dx = ex * anx + da1 * cx; R.dfy_dx = ex * any + da1 * cy;
+  R.dfx_dy = ey * anx + da2 * cx; R.dfy_dy = ey * any + da2 * cy;
+  return R;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Bicubic interpolation of the u8 costmap with clamp-to-edge, value and gradient
 // (ceres::BiCubicInterpolator<Grid2D<u_char>> semantics; used by
@@ -320,7 +389,7 @@ struct Ctx {
   bool has_people;
   const uint8_t* map;
   double* lds;       // this slot's LDS block (scene constants, cos/sin block, LM state live here)
-  double* ag;        // staged people block [N][T][4] of this slot (LDS in K1, global workspace in the solve kernel)
+  const double* ag;  // staged people records [N][T][4] of this slot's scene (global memory)
   double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
   LdsLayout L;
 };
@@ -356,10 +425,88 @@ struct GramView {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// Load the slot's scene constants, stage its people block (one 32-byte record px, py, vx, vy per (agent, step), record
-// index a * T + t) into c.ag and the valid
-// mask per step into LDS, compute the agent-angle tags. Executed by all W lanes of the slot (other slots may be
-// masked off).
+// Staging pass (its own kernel, once per people block): gather the slot's people block, agent index fastest across
+// lanes (coalesced runs of one people row, 16 loads in flight per lane), convert to one 32-byte record (px, py, vx, vy)
+// per (agent, step) at record index a * T + t in LDS (ag), and compute per step the bit mask of valid agents (vmask)
+// and the agent-angle tag (aa). Executed by all W lanes of the slot.
+template <int W>
+__device__ inline void stage_people(KParamsK kp, int scene, int sl, double* ag, unsigned long long* vmask, double* aa) {
+  const auto& k = *kp;
+  const int T = k.T, N = k.N;
+  const size_t s = scene;
+  const double x0 = k.pose0[3 * s], y0 = k.pose0[3 * s + 1], yaw0 = k.pose0[3 * s + 2];
+  const double* ppl = k.people + s * (size_t)(T + 1) * 6 * N;
+  const int TN = T * N;
+  // people_proj[t+1] field f agent a is at ((t+1)*6 + f)*N + a. Element (a, t) lands at a*T + t.
+  for (int e0 = sl; e0 < TN; e0 += 4 * W) {
+    double gx[4], gy[4], gyaw[4], glv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + u * W, TN - 1);
+      const int t = e / N, a = e - t * N;
+      const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
+      gx[u] = f[0]; gy[u] = f[N]; gyaw[u] = f[2 * N]; glv[u] = f[4 * N];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * W;
+      if (e < TN) {
+        const int t = e / N, a = e - t * N;
+        double sn, cs;
+        if (__builtin_expect(!(fabs(gyaw[u]) <= 1e5), 0)) sincos(gyaw[u], &sn, &cs);
+        else sincos_tab(&k.mt, gyaw[u], &sn, &cs);
+        const int q = a * T + t;
+        v4d rec = {gx[u], gy[u], glv[u] * cs, glv[u] * sn};  // aVel, social_work:187-188
+        reinterpret_cast<v4d*>(ag)[q] = rec;
+      }
+    }
+  }
+  if (sl < T) {
+    const double* f = ppl + (size_t)(sl + 1) * 6 * N;
+    unsigned long long m = 0;
+    double aa_target = kNoTarget;
+    // a7 AgentAngle tag: depends on constants only (critics/agent_angle_cost_function.hpp:130-190)
+    int closest = -1;
+    double best = INFINITY;
+    for (int a0 = 0; a0 < N; a0 += 4) {  // loads of four agents in flight at a time
+      double ft[4], fx[4], fy[4], fl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = min(a0 + u, N - 1);
+        ft[u] = f[3 * N + a]; fx[u] = f[a]; fy[u] = f[N + a]; fl[u] = f[4 * N + a];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = a0 + u;
+        if (a < N) {
+          if (ft[u] != -1.0) m |= (1ull << a);  // social_work:175
+          const double ddx = fx[u] - x0, ddy = fy[u] - y0;
+          const double d2 = ddx * ddx + ddy * ddy;
+          if (d2 < best && fl[u] > 0.05) { best = d2; closest = a; }
+        }
+      }
+    }
+    if (closest >= 0 && !(best > 4.0)) {
+      const double ax = f[closest], ay = f[N + closest], ayaw = f[2 * N + closest];
+      const double agent_angle_initial = atan2(ay - y0, ax - x0);
+      // atan2(sin u, cos u) of the reference (:148-152) restated as the range reduction wrap_angle(u)
+      const double heading_diff = wrap_angle(ayaw - yaw0);
+      const double rel = wrap_angle(agent_angle_initial - yaw0);
+      const double kThr = M_PI / 6.0, kUp = 5 * M_PI / 6.0;
+      if (heading_diff <= -kUp || heading_diff >= kThr) {
+        if (!(rel < 0.0)) aa_target = yaw0 + (-(M_PI / 6.0));
+      } else {
+        if (!(rel > 0.0)) aa_target = yaw0 + (M_PI / 6.0);
+      }
+    }
+    vmask[sl] = m;
+    aa[sl] = aa_target;
+  }
+}
+
+// Load the slot's scene constants and the per-step side data of its staged people block (valid masks, agent-angle
+// tags) into LDS; the records themselves stay in global memory (c.ag). Executed by all W lanes of the slot (other
+// slots may be masked off).
 template <int W>
 __device__ inline void load_scene(Ctx& c, int scene) {
   const auto& k = *c.kp;
@@ -367,6 +514,7 @@ __device__ inline void load_scene(Ctx& c, int scene) {
   const size_t s = scene;
   c.scene = scene;
   c.has_people = (N > 0) && (k.has_people ? k.has_people[s] != 0 : true);
+  c.ag = k.people_rec + s * (size_t)4 * T * (N > 0 ? N : 1);
   const double x0 = k.pose0[3 * s], y0 = k.pose0[3 * s + 1], yaw0 = k.pose0[3 * s + 2];
   const size_t cm = (size_t)k.size_x * k.size_y;
   c.map = k.costmap + (k.costmap_shared ? 0 : cm * s);
@@ -379,79 +527,13 @@ __device__ inline void load_scene(Ctx& c, int scene) {
   cst[6] = path_pts[2 * T];
   cst[7] = path_pts[2 * T + 1];
   double* lanec = c.lds + c.L.lanec;
-  double aa_target = kNoTarget;
-  if (c.has_people) {
-    double* ag = c.ag;
-    unsigned long long* vmask = reinterpret_cast<unsigned long long*>(c.lds + c.L.valid);
-    const double* ppl = k.people + s * (size_t)(T + 1) * 6 * N;
-    const int TN = T * N;
-    // people_proj[t+1] field f agent a is at ((t+1)*6 + f)*N + a. Gather with the agent index fastest across lanes
-    // (neighbouring lanes read neighbouring doubles of one people row); element (a, t) lands at a*T + t of each plane.
-    // Four elements per trip, all 16 loads issued before the first use (the stand-alone K1 kernel is bound by this
-    // chain of HBM latencies otherwise).
-    for (int e0 = sl; e0 < TN; e0 += 4 * W) {
-      double gx[4], gy[4], gyaw[4], glv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = min(e0 + u * W, TN - 1);
-        const int t = e / N, a = e - t * N;
-        const double* f = ppl + (size_t)(t + 1) * 6 * N + a;
-        gx[u] = f[0]; gy[u] = f[N]; gyaw[u] = f[2 * N]; glv[u] = f[4 * N];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * W;
-        if (e < TN) {
-          const int t = e / N, a = e - t * N;
-          double sn, cs;
-          sincos(gyaw[u], &sn, &cs);
-          const int q = a * T + t;
-          v4d rec = {gx[u], gy[u], glv[u] * cs, glv[u] * sn};  // aVel, social_work:187-188
-          reinterpret_cast<v4d*>(ag)[q] = rec;  // one 32-byte record (px, py, vx, vy) per (agent, step)
-        }
-      }
-    }
-    if (sl < T) {
-      const double* f = ppl + (size_t)(sl + 1) * 6 * N;
-      unsigned long long m = 0;
-      // a7 AgentAngle tag: depends on constants only (critics/agent_angle_cost_function.hpp:130-190)
-      int closest = -1;
-      double best = INFINITY;
-      for (int a0 = 0; a0 < N; a0 += 4) {  // loads of four agents in flight at a time
-        double ft[4], fx[4], fy[4], fl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int a = min(a0 + u, N - 1);
-          ft[u] = f[3 * N + a]; fx[u] = f[a]; fy[u] = f[N + a]; fl[u] = f[4 * N + a];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int a = a0 + u;
-          if (a < N) {
-            if (ft[u] != -1.0) m |= (1ull << a);  // social_work:175
-            const double ddx = fx[u] - x0, ddy = fy[u] - y0;
-            const double d2 = ddx * ddx + ddy * ddy;
-            if (d2 < best && fl[u] > 0.05) { best = d2; closest = a; }
-          }
-        }
-      }
-      vmask[sl] = m;
-      if (closest >= 0 && !(best > 4.0)) {
-        const double ax = f[closest], ay = f[N + closest], ayaw = f[2 * N + closest];
-        const double agent_angle_initial = atan2(ay - y0, ax - x0);
-        // atan2(sin u, cos u) of the reference (:148-152) restated as the range reduction wrap_angle(u)
-        const double heading_diff = wrap_angle(ayaw - yaw0);
-        const double rel = wrap_angle(agent_angle_initial - yaw0);
-        const double kThr = M_PI / 6.0, kUp = 5 * M_PI / 6.0;
-        if (heading_diff <= -kUp || heading_diff >= kThr) {
-          if (!(rel < 0.0)) aa_target = yaw0 + (-(M_PI / 6.0));
-        } else {
-          if (!(rel > 0.0)) aa_target = yaw0 + (M_PI / 6.0);
-        }
-      }
-    }
-  }
   if (sl < T) {
+    double aa_target = kNoTarget;
+    if (c.has_people) {
+      const double* aux = k.people_aux + (s * T + sl) * 2;
+      (c.lds + c.L.valid)[sl] = aux[0];  // the mask's bits travel in a double-sized slot
+      aa_target = aux[1];
+    }
     lanec[sl] = path_pts[2 * (sl + 1)];
     lanec[T + sl] = path_pts[2 * (sl + 1) + 1];
     lanec[2 * T + sl] = aa_target;
@@ -478,6 +560,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   const int myb = (sl < CH) ? sl / bl : blast;  // block driving step sl
   const double vb = xp[2 * myb], wb = xp[2 * myb + 1];
 
+  // staged people records of this lane's step: agent a at agr[a * T]; the first two are requested now, so that their
+  // latency (HBM in the stand-alone K1 kernel) passes behind the rollout
+  const v4d* agr = reinterpret_cast<const v4d*>(c.ag) + tl;
+  v4d rec0 = {0.0, 0.0, 0.0, 0.0}, rec1 = {0.0, 0.0, 0.0, 0.0};
+  if (c.has_people) { rec0 = agr[0]; rec1 = agr[(N > 1 ? 1 : 0) * T]; }
+
   // ---- a1 rollout, block-structured. theta_sl by sequential adds in the reference's order (:46-61).
   double th = cst[2];
   {
@@ -493,7 +581,10 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   }
   {
     double sn, cs;
-    sincos(th, &sn, &cs);
+    // headings of a rollout are modest numbers; the library routine (Payne-Hanek reduction) only for a lane that holds a
+    // heading beyond the two-part Cody-Waite range (an unbounded last parameter block can produce one)
+    if (__builtin_expect(!(fabs(th) <= 1e5), 0)) sincos(th, &sn, &cs);
+    else sincos_tab(&k.mt, th, &sn, &cs);
     if (sl <= T) { cs_[sl] = cs; sn_[sl] = sn; }
   }
   const double th1 = th + wb * dt;  // theta_{sl+1}: the same add the reference performs at step sl
@@ -532,56 +623,87 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   double pbest = 1.7976931348623157e308, pdx = 0.0, pdy = 0.0;
   if (c.has_people) {
     double su[4] = {0.0, 0.0, 0.0, 0.0};  // sums over valid agents of dF/du: (fx,ux) (fy,ux) (fx,uy) (fy,uy)
-    double qh[4] = {0.0, 0.0, 0.0, 0.0};  // sums over regular pairs of F . dF/d(x, y, ux, uy)
-    const double* ag = c.ag;
+    double qh[4] = {0.0, 0.0, 0.0, 0.0};  // sums over pairs of F . dF/d(x, y, ux, uy), agent side
+    const MathTabP mt = &k.mt;
     const unsigned long long* vmask = reinterpret_cast<const unsigned long long*>(c.lds + c.L.valid);
-    const int TN = T * N;
     const unsigned long long vm = vmask[tl];
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
-    // software prefetch of the next agent's entry of the staged block (L2-resident workspace in the solve kernel,
-    // LDS in the stand-alone K1 kernel)
-    const v4d* agr = reinterpret_cast<const v4d*>(ag) + tl;  // records of this lane's step: agent a at agr[a * T]
-    v4d nrec = agr[0];
-#pragma unroll 2  // two agents per trip: measured +4% on the fused solve kernel (more independent work per wave)
+    int pidx = 0;  // proxemics: index of the nearest valid agent (first minimum wins: std::min on duals)
+    bool redo = false;  // some pair of this lane is not a regular one
     for (int a = 0; a < N; ++a) {
-      const double apx = nrec[0], apy = nrec[1], awx = nrec[2], awy = nrec[3];
-      if (a + 1 < N) nrec = agr[(a + 1) * T];
+      // records are fetched two agents ahead (the first two before the rollout, above): HBM latency in K1, L2 in a solve
+      const double apx = rec0[0], apy = rec0[1], awx = rec0[2], awy = rec0[3];
+      rec0 = rec1;
+      if (a + 2 < N) rec1 = agr[(a + 2) * T];
       const bool valid = (vm >> a) & 1ull;
       const double dx = X - apx, dy = Y - apy;
-      const double d2 = dx * dx + dy * dy;
-      const bool degenerate = d2 < 1e-12;  // |diff| < 1e-6
-      if (valid) {
-        if (d2 < pbest) { pbest = d2; pdx = dx; pdy = dy; }  // proxemics: first minimum wins (std::min on duals)
-        // force on the robot from this agent (:125): diff = robot - agent, u = robotVel - agentVel
-        const Force F = social_force(dx, dy, rvx - awx, rvy - awy);
-        soc[0] += F.fx; soc[1] += F.fy;
-        soc[2] += F.dfx_dx; soc[3] += F.dfy_dx; soc[4] += F.dfx_dy; soc[5] += F.dfy_dy;
-        // derivatives with respect to the robot's (theta, v) are one rotation of the u-derivatives that is the same
-        // for every agent of this step (u = v (cos theta, sin theta) - agentVel): sum the u-derivatives, rotate once
-        // after the loop
-        su[0] += F.dfx_dux; su[1] += F.dfy_dux; su[2] += F.dfx_duy; su[3] += F.dfy_duy;
-        if (!degenerate) {
-          // force on the agent from the robot (:137-143) is exactly -F for a non-degenerate pair: |F|^2 and the
-          // halves of its derivatives (doubled, and the u-parts rotated, after the loop)
-          soc[10] = fma(F.fx, F.fx, fma(F.fy, F.fy, soc[10]));
-          qh[0] = fma(F.fx, F.dfx_dx, fma(F.fy, F.dfy_dx, qh[0]));
-          qh[1] = fma(F.fx, F.dfx_dy, fma(F.fy, F.dfy_dy, qh[1]));
-          qh[2] = fma(F.fx, F.dfx_dux, fma(F.fy, F.dfy_dux, qh[2]));
-          qh[3] = fma(F.fx, F.dfx_duy, fma(F.fy, F.dfy_duy, qh[3]));
+      const double d2 = fma(dx, dx, dy * dy);
+      const bool nearer = valid & (d2 < pbest);
+      pbest = nearer ? d2 : pbest;
+      pidx = nearer ? a : pidx;
+      // One evaluation serves both directions: the force on the robot from the agent (:125; valid agents only, :175)
+      // is F(diff, u), diff = robot - agent, u = robotVel - agentVel; the force on the agent from the robot
+      // (:137-143; every column, phantoms included) is F(-diff, -u) = -F with the same derivatives, so |.|^2 and its
+      // gradient are those of F.
+      const Force F = pair_force(mt, dx, dy, rvx - awx, rvy - awy);
+      redo |= F.special | (d2 < 1e-12);  // |diff| < 1e-6 -> diff := (1e-6, 0), :181-184, breaks the symmetry above
+      const double m = valid ? 1.0 : 0.0;
+      soc[0] = fma(m, F.fx, soc[0]); soc[1] = fma(m, F.fy, soc[1]);
+      soc[2] = fma(m, F.dfx_dx, soc[2]); soc[3] = fma(m, F.dfy_dx, soc[3]);
+      soc[4] = fma(m, F.dfx_dy, soc[4]); soc[5] = fma(m, F.dfy_dy, soc[5]);
+      // derivatives with respect to the robot's (theta, v) are one rotation of the u-derivatives that is the same
+      // for every agent of this step (u = v (cos theta, sin theta) - agentVel): sum the u-derivatives, rotate once
+      // after the loop
+      su[0] = fma(m, F.dfx_dux, su[0]); su[1] = fma(m, F.dfy_dux, su[1]);
+      su[2] = fma(m, F.dfx_duy, su[2]); su[3] = fma(m, F.dfy_duy, su[3]);
+      soc[10] = fma(F.fx, F.fx, fma(F.fy, F.fy, soc[10]));
+      qh[0] = fma(F.fx, F.dfx_dx, fma(F.fy, F.dfy_dx, qh[0]));
+      qh[1] = fma(F.fx, F.dfx_dy, fma(F.fy, F.dfy_dy, qh[1]));
+      qh[2] = fma(F.fx, F.dfx_dux, fma(F.fy, F.dfy_dux, qh[2]));
+      qh[3] = fma(F.fx, F.dfx_duy, fma(F.fy, F.dfy_duy, qh[3]));
+    }
+    if (__builtin_expect(redo, 0)) {
+      // Rare: this lane met a pair the fast form does not cover. It walks its agents again in the general form (both
+      // directions evaluated where the symmetry does not hold), from cleared sums. Decided per lane: the result of a
+      // scene must not depend on which other scene shares its wave.
+#pragma unroll
+      for (int i = 0; i < kSoc; ++i) soc[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { su[i] = 0.0; qh[i] = 0.0; }
+      for (int a = 0; a < N; ++a) {
+        const v4d rec = agr[a * T];
+        const double apx = rec[0], apy = rec[1], awx = rec[2], awy = rec[3];
+        const bool valid = (vm >> a) & 1ull;
+        const double dx = X - apx, dy = Y - apy;
+        const double d2 = dx * dx + dy * dy;
+        const bool degenerate = d2 < 1e-12;
+        if (valid) {
+          const Force F = social_force_general(dx, dy, rvx - awx, rvy - awy);
+          soc[0] += F.fx; soc[1] += F.fy;
+          soc[2] += F.dfx_dx; soc[3] += F.dfy_dx; soc[4] += F.dfx_dy; soc[5] += F.dfy_dy;
+          su[0] += F.dfx_dux; su[1] += F.dfy_dux; su[2] += F.dfx_duy; su[3] += F.dfy_duy;
+          if (!degenerate) {
+            soc[10] = fma(F.fx, F.fx, fma(F.fy, F.fy, soc[10]));
+            qh[0] = fma(F.fx, F.dfx_dx, fma(F.fy, F.dfy_dx, qh[0]));
+            qh[1] = fma(F.fx, F.dfx_dy, fma(F.fy, F.dfy_dy, qh[1]));
+            qh[2] = fma(F.fx, F.dfx_dux, fma(F.fy, F.dfy_dux, qh[2]));
+            qh[3] = fma(F.fx, F.dfx_duy, fma(F.fy, F.dfy_duy, qh[3]));
+          }
+        }
+        if (!valid || degenerate) {
+          const Force G = social_force_general(-dx, -dy, awx - rvx, awy - rvy);
+          soc[10] += G.fx * G.fx + G.fy * G.fy;
+          // d/d(robot x, y) = -d/d(diff), d/d(robot u) = -d/d(u): entered with the sign, rotated with the rest below
+          qh[0] -= G.fx * G.dfx_dx + G.fy * G.dfy_dx;
+          qh[1] -= G.fx * G.dfx_dy + G.fy * G.dfy_dy;
+          qh[2] -= G.fx * G.dfx_dux + G.fy * G.dfy_dux;
+          qh[3] -= G.fx * G.dfx_duy + G.fy * G.dfy_duy;
         }
       }
-      if (!valid || degenerate) {
-        // phantom (invalid column, :137 loops every column) or coincident pair: force on the agent from the
-        // robot evaluated on its own (diff = agent - robot, u = agentVel - robotVel); signs flip through diff, u.
-        const Force G = social_force(-dx, -dy, awx - rvx, awy - rvy);
-        const double gx_th = -vb * (-s1 * G.dfx_dux + c1 * G.dfx_duy), gy_th = -vb * (-s1 * G.dfy_dux + c1 * G.dfy_duy);
-        const double gx_v = -(c1 * G.dfx_dux + s1 * G.dfx_duy), gy_v = -(c1 * G.dfy_dux + s1 * G.dfy_duy);
-        soc[10] += G.fx * G.fx + G.fy * G.fy;
-        soc[11] += -2.0 * (G.fx * G.dfx_dx + G.fy * G.dfy_dx);
-        soc[12] += -2.0 * (G.fx * G.dfx_dy + G.fy * G.dfy_dy);
-        soc[13] += 2.0 * (G.fx * gx_th + G.fy * gy_th);
-        soc[14] += 2.0 * (G.fx * gx_v + G.fy * gy_v);
-      }
+    }
+    {
+      const v4d prec = agr[pidx * T];
+      pdx = X - prec[0]; pdy = Y - prec[1];
     }
     soc[6] = vb * (-s1 * su[0] + c1 * su[2]); soc[7] = vb * (-s1 * su[1] + c1 * su[3]);  // d(sum F)/d theta
     soc[8] = c1 * su[0] + s1 * su[2]; soc[9] = c1 * su[1] + s1 * su[3];                  // d(sum F)/d v
@@ -727,7 +849,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     }
     // a4 proxemics: w alpha exp(-min_a d^2 / d0^2) over valid agents
     {
-      const double e = 3.0 * exp(-pbest / (0.5 * 0.5));
+      const double e = 3.0 * exp_tab(&k.mt, -pbest / (0.5 * 0.5));
       const double r = w.proxemics_w * e;
       double gx = r * (-2.0 * pdx / (0.5 * 0.5)), gy = r * (-2.0 * pdy / (0.5 * 0.5));
       if (pbest == 1.7976931348623157e308) {

@@ -54,6 +54,28 @@ Dims make_dims(const smpc_params& p, int T, bool has_people) {
 
 }  // namespace
 
+namespace smpc {
+struct ProbeParams { int fn, n; const double* a; const double* b; double* o0; double* o1; MathTab mt; };
+__global__ void smpc_math_probe_kernel(const ProbeParams) {
+  const auto& k = *(const ProbeParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= k.n) return;
+  const double a = k.a[i], b = k.b ? k.b[i] : 0.0;
+  double r0 = 0.0, r1 = 0.0;
+  switch (k.fn) {
+    case 0: r0 = exp_tab(&k.mt, a); break;
+    case 1: r0 = atan2_dir(&k.mt, a, b); break;
+    case 2: sincos_tab(&k.mt, a, &r0, &r1); break;
+    case 3: r0 = rsqrt_pos(a); break;
+    case 4: r0 = div_fast(a, b); break;
+    case 5: r0 = rcp_estimate(a); break;
+    default: r0 = rsq_estimate(a); break;
+  }
+  k.o0[i] = r0;
+  if (k.o1) k.o1[i] = r1;
+}
+}  // namespace smpc
+
 struct smpc_handle {
   smpc_params prm;
   int device;
@@ -62,8 +84,9 @@ struct smpc_handle {
   hipEvent_t ev0, ev1;
   bool timed;
   int* queue;  // device-side scene queue head
-  double* ws_ag;  // staged-people workspace of the persistent solve kernel
-  size_t ws_ag_bytes;
+  double* stage_rec;  // staged people block of the latest call that did not bring its own (grow-only)
+  double* stage_aux;
+  size_t stage_rec_bytes, stage_aux_bytes;
   char* stage;        // grow-only arena for host-pointer calls (the plugin's B = 1 use): no hipMalloc per call
   size_t stage_cap;
   size_t stage_want;  // high-water mark of the calls so far
@@ -95,7 +118,8 @@ int validate(const smpc_handle* h, const smpc_scene_batch* sb, Dims* d) {
   if (sb->B < 0 || sb->T < 1 || sb->N < 0) { set_error("bad B/T/N"); return SMPC_ERR_INVALID_ARG; }
   if (h->prm.control_horizon < 1 || h->prm.parameter_block_length < 1) { set_error("control_horizon and parameter_block_length must be >= 1"); return SMPC_ERR_INVALID_ARG; }
   if (!sb->pose0 || !sb->init_params || !sb->path_pts || !sb->goal_yaw || !sb->costmap || !sb->costmap_origin) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
-  if (sb->N > 0 && !sb->people) { set_error("people is null with N > 0"); return SMPC_ERR_INVALID_ARG; }
+  if ((sb->people_records != nullptr) != (sb->people_aux != nullptr)) { set_error("people_records and people_aux go together"); return SMPC_ERR_INVALID_ARG; }
+  if (sb->N > 0 && !sb->people && !sb->people_records) { set_error("people is null with N > 0"); return SMPC_ERR_INVALID_ARG; }
   if (sb->size_x < 1 || sb->size_y < 1 || !(sb->resolution > 0.0)) { set_error("bad costmap geometry"); return SMPC_ERR_INVALID_ARG; }
   *d = make_dims(h->prm, sb->T, true);
   if (sb->T + 1 > smpc::kWave) { set_error("T + 1 > 64 rollout poses is not supported by the one-wave-per-scene mapping"); return SMPC_ERR_UNSUPPORTED; }
@@ -112,6 +136,7 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
   k->dt = sb->dt; k->resolution = sb->resolution;
   k->prm = h->prm;
   k->e_M = d.M;
+  smpc::fill_math_table(&k->mt);
 }
 
 #define SMPC_TRY_(expr) do { int _rc = (expr); if (_rc != SMPC_OK) return _rc; } while (0)
@@ -167,13 +192,56 @@ struct Staging {
 
 #define SMPC_TRY(expr) do { int _rc = (expr); if (_rc != SMPC_OK) return _rc; } while (0)
 
+int grow(double** buf, size_t* have, size_t need, hipStream_t st) {
+  if (need <= *have) return SMPC_OK;
+  SMPC_HIP_CHECK(hipStreamSynchronize(st));  // nothing of an earlier call may still read the old buffer
+  if (*buf) SMPC_HIP_CHECK(hipFree(*buf));
+  *buf = nullptr; *have = 0;
+  SMPC_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(buf), need));
+  *have = need;
+  return SMPC_OK;
+}
+
+// The staging pass: k.people (+ pose0, has_people) -> records / aux at the given device pointers.
+int launch_stage(smpc_handle* h, smpc::KParams& k, double* rec, double* aux) {
+  if (k.B == 0 || k.N == 0) return SMPC_OK;
+  const int W = smpc::slot_width(k.T, k.N);
+  const int S = smpc::kWave / W;
+  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, 2, smpc::kLayoutStage);
+  const size_t shmem = (size_t)S * L.total * sizeof(double);
+  KernelFn fn = (W == 32) ? smpc::smpc_stage_kernel<32> : smpc::smpc_stage_kernel<64>;
+  if (shmem > 160 * 1024) { set_error("people block does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
+  if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  k.stage_rec = rec; k.stage_aux = aux;
+  hipLaunchKernelGGL(fn, dim3((k.B + S - 1) / S), dim3(smpc::kWave), shmem, h->stream, k);
+  SMPC_HIP_CHECK(hipGetLastError());
+  return SMPC_OK;
+}
+
+// Makes k.people_rec / k.people_aux valid: the caller's staged block, or the library's own staging pass into the
+// handle's buffers (timed separately: smpc_last_kernel_ms() reports the solve / sweep kernel alone).
+int bind_people(smpc_handle* h, const smpc_scene_batch* sb, smpc::KParams& k, Staging* st) {
+  if (sb->N == 0) return SMPC_OK;
+  const size_t nrec = (size_t)sb->B * sb->N * sb->T * 4, naux = (size_t)sb->B * sb->T * 2;
+  if (sb->people_records) {
+    if (sb->on_device) { k.people_rec = sb->people_records; k.people_aux = sb->people_aux; return SMPC_OK; }
+    SMPC_TRY_(st->up(sb->people_records, nrec, &k.people_rec, h->stream));
+    SMPC_TRY_(st->up(sb->people_aux, naux, &k.people_aux, h->stream));
+    return SMPC_OK;
+  }
+  SMPC_TRY_(grow(&h->stage_rec, &h->stage_rec_bytes, nrec * sizeof(double), h->stream));
+  SMPC_TRY_(grow(&h->stage_aux, &h->stage_aux_bytes, naux * sizeof(double), h->stream));
+  SMPC_TRY_(launch_stage(h, k, h->stage_rec, h->stage_aux));
+  k.people_rec = h->stage_rec; k.people_aux = h->stage_aux;
+  return SMPC_OK;
+}
+
 int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   const int W = smpc::slot_width(k.T, k.N);
   const int S = smpc::kWave / W;
   KernelFn fn = pick(k.nb, W, eval);
-  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, !eval);
-  const bool overlay = eval && smpc::k1_tiles_overlay_people(k.T, k.N, k.P, W);
-  const size_t shmem = ((size_t)S * L.total + (overlay ? 0 : smpc::wave_extra_doubles(k.P, W))) * sizeof(double);
+  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve);
+  const size_t shmem = ((size_t)S * L.total + smpc::wave_extra_doubles(k.P, W)) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
   if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (k.B == 0) return SMPC_OK;
@@ -191,15 +259,6 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     if (grid > resident) grid = resident;
     k.queue = h->queue;
     SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
-    const size_t need = (size_t)grid * S * 4 * k.T * (k.N > 0 ? k.N : 1) * sizeof(double);
-    if (need > h->ws_ag_bytes) {  // grows on first use / on a larger shape only; reused by every later launch
-      SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
-      if (h->ws_ag) SMPC_HIP_CHECK(hipFree(h->ws_ag));
-      h->ws_ag = nullptr; h->ws_ag_bytes = 0;
-      SMPC_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&h->ws_ag), need));
-      h->ws_ag_bytes = need;
-    }
-    k.ws_ag = h->ws_ag;
   }
 #ifdef SMPC_STAMPS
   {  // diagnostic build: per-wave phase cycle sums, dumped to stderr after the launch
@@ -243,7 +302,7 @@ int bind_inputs(smpc_handle* h, const smpc_scene_batch* sb, const Dims& d, smpc:
   SMPC_TRY(st->up(sb->init_params, B * d.P, &k->init_params, h->stream));
   SMPC_TRY(st->up(sb->path_pts, B * (T + 1) * 2, &k->path_pts, h->stream));
   SMPC_TRY(st->up(sb->goal_yaw, B, &k->goal_yaw, h->stream));
-  SMPC_TRY(st->up(sb->people, B * (T + 1) * 6 * N, &k->people, h->stream));
+  if (!sb->people_records) SMPC_TRY(st->up(sb->people, B * (T + 1) * 6 * N, &k->people, h->stream));
   SMPC_TRY(st->up(sb->has_people, B, &k->has_people, h->stream));
   SMPC_TRY(st->up(sb->costmap, nmaps * (size_t)sb->size_x * sb->size_y, &k->costmap, h->stream));
   SMPC_TRY(st->up(sb->costmap_origin, nmaps * 2, &k->costmap_origin, h->stream));
@@ -307,8 +366,9 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
   h->stream = nullptr;
   h->timed = false;
   h->queue = nullptr;
-  h->ws_ag = nullptr;
-  h->ws_ag_bytes = 0;
+  h->stage_rec = nullptr;
+  h->stage_aux = nullptr;
+  h->stage_rec_bytes = h->stage_aux_bytes = 0;
   h->stage = nullptr;
   h->stage_cap = 0;
   h->stage_want = 0;
@@ -325,7 +385,8 @@ void smpc_destroy(smpc_handle* h) {
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
   if (h->queue) (void)hipFree(h->queue);
-  if (h->ws_ag) (void)hipFree(h->ws_ag);
+  if (h->stage_rec) (void)hipFree(h->stage_rec);
+  if (h->stage_aux) (void)hipFree(h->stage_aux);
   if (h->stage) (void)hipFree(h->stage);
   delete h;
 }
@@ -353,6 +414,7 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   fill_kparams(h, sb, d, &k);
   Staging st(h);
   SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
+  SMPC_TRY(bind_people(h, sb, k, &st));
   const size_t B = sb->B, T = sb->T;
   if (sb->on_device) {
     k.o_params = out->params; k.o_cmds = out->cmds; k.o_path = out->path; k.o_status = out->status; k.o_reason = out->reason;
@@ -658,6 +720,67 @@ int smpc_select_command_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t tra
   return SMPC_OK;
 }
 
+int smpc_stage_people_batch(smpc_handle* h, const smpc_scene_batch* sb, double* records, double* aux) {
+  if (!h || !sb || !records || !aux) { set_error("null handle / scene batch / output"); return SMPC_ERR_INVALID_ARG; }
+  if (sb->B < 0 || sb->T < 1 || sb->N < 1) { set_error("bad B/T/N"); return SMPC_ERR_INVALID_ARG; }
+  if (sb->T + 1 > smpc::kWave || sb->N > smpc::kWave) { set_error("T + 1 > 64 or N > 64 is not supported"); return SMPC_ERR_UNSUPPORTED; }
+  if (!sb->pose0 || !sb->people) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  smpc::KParams k;
+  std::memset(&k, 0, sizeof(k));
+  k.B = sb->B; k.T = sb->T; k.N = sb->N;
+  smpc::fill_math_table(&k.mt);
+  const size_t B = sb->B, T = sb->T, N = sb->N;
+  const size_t nrec = B * N * T * 4, naux = B * T * 2;
+  Staging st(h);
+  double *drec = records, *daux = aux;
+  if (sb->on_device) {
+    k.pose0 = sb->pose0; k.people = sb->people; k.has_people = sb->has_people;
+  } else {
+    SMPC_TRY(st.up(sb->pose0, B * 3, &k.pose0, h->stream));
+    SMPC_TRY(st.up(sb->people, B * (T + 1) * 6 * N, &k.people, h->stream));
+    SMPC_TRY(st.up(sb->has_people, B, &k.has_people, h->stream));
+    SMPC_TRY(st.out(records, nrec, &drec));
+    SMPC_TRY(st.out(aux, naux, &daux));
+    SMPC_HIP_CHECK(hipMemsetAsync(drec, 0, nrec * sizeof(double), h->stream));  // scenes without people: defined bytes
+    SMPC_HIP_CHECK(hipMemsetAsync(daux, 0, naux * sizeof(double), h->stream));
+  }
+  SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+  SMPC_TRY(launch_stage(h, k, drec, daux));
+  SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+  h->timed = true;
+  if (!sb->on_device) {
+    SMPC_TRY(down(records, drec, nrec, h->stream));
+    SMPC_TRY(down(aux, daux, naux, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
+int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1) {
+  if (!h || !a || !out0 || n < 0 || fn < 0 || fn > 6) { set_error("bad arguments to smpc_math_probe"); return SMPC_ERR_INVALID_ARG; }
+  if ((fn == 1 || fn == 4) && !b) { set_error("second argument array is null"); return SMPC_ERR_INVALID_ARG; }
+  if (fn == 2 && !out1) { set_error("out1 is null for sincos"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  smpc::ProbeParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.fn = fn; p.n = n;
+  smpc::fill_math_table(&p.mt);
+  Staging st(h);
+  SMPC_TRY(st.up(a, (size_t)n, &p.a, h->stream));
+  SMPC_TRY(st.up(b, (size_t)n, &p.b, h->stream));
+  SMPC_TRY(st.out(out0, (size_t)n, &p.o0));
+  SMPC_TRY(st.out(out1, (size_t)n, &p.o1));
+  if (n > 0) {
+    hipLaunchKernelGGL(smpc::smpc_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+  }
+  SMPC_TRY(down(out0, p.o0, (size_t)n, h->stream));
+  SMPC_TRY(down(out1, p.o1, (size_t)n, h->stream));
+  SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  return SMPC_OK;
+}
+
 int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* params, smpc_eval_batch_out* out) {
   Dims d;
   SMPC_TRY(validate(h, sb, &d));
@@ -667,6 +790,7 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* pa
   fill_kparams(h, sb, d, &k);
   Staging st(h);
   SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
+  SMPC_TRY(bind_people(h, sb, k, &st));
   const size_t B = sb->B;
   if (sb->on_device) {
     k.e_x = params;

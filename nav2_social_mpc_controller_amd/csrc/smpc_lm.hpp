@@ -512,11 +512,11 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   Ctx c;
   c.kp = &k;
   c.sl = lane - slot * W;
-  c.L = make_layout(k.T, k.N, P, true);
+  c.L = make_layout(k.T, k.N, P, kLayoutSolve);
   c.lds = lds_all + (size_t)slot * c.L.total;
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
-  c.ag = k.ws_ag + ((size_t)blockIdx.x * S + slot) * 4 * k.T * (k.N > 0 ? k.N : 1);
+  c.ag = k.people_rec;
   const auto& prm = k.prm;
   const int T = k.T;
   double* Hs = c.lds + c.L.lm;   // [P*P reserved] scaled J^T J at the current point, packed lower triangle tri(i, j)
@@ -848,11 +848,11 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
   Ctx c;
   c.kp = &k;
   c.sl = lane - slot * W;
-  c.L = make_layout(k.T, k.N, P, false);
+  c.L = make_layout(k.T, k.N, P, kLayoutEval);
   c.lds = lds_all + (size_t)slot * c.L.total;
-  c.wave_lds = k1_tiles_overlay_people(k.T, k.N, P, W) ? lds_all + c.L.ag : lds_all + (size_t)S * c.L.total;
+  c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
-  c.ag = c.lds + c.L.ag;  // staged people block in LDS
+  c.ag = k.people_rec;
 #ifdef SMPC_STAMPS
   for (int i = 0; i < 8; ++i) c.acc[i] = 0;
   for (int i = 0; i < 4; ++i) c.acc2[i] = 0;
@@ -883,6 +883,42 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
     for (int i = 0; i < 4; ++i) k.stamps[(size_t)blockIdx.x * 12 + 8 + i] = c.acc2[i];
   }
 #endif
+}
+
+// Staging pass: people block of the reference layout ([T+1][6][N] per scene) -> the records the sweep reads
+// ([N][T] x (px, py, vx, vy), written as whole 128-byte lines through LDS) + per-step valid mask and agent-angle tag.
+// One slot per scene like the sweep kernels; once per people block (a solve re-reads the records ~50 times).
+template <int W>
+__global__ __launch_bounds__(64) void smpc_stage_kernel(const KParams) {
+  const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
+  constexpr int S = kWave / W;
+  extern __shared__ __attribute__((aligned(32))) double lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int slot = lane / W, sl = lane - slot * W;
+  const int T = k.T, N = k.N;
+  const LdsLayout L = make_layout(T, N, 2, kLayoutStage);
+  double* lds = lds_all + (size_t)slot * L.total;
+  const int scene_raw = blockIdx.x * S + slot;
+  const bool live = scene_raw < k.B;
+  const int scene = live ? scene_raw : k.B - 1;
+  const bool has_people = k.has_people ? k.has_people[scene] != 0 : true;
+  double* ag = lds + L.ag;
+  unsigned long long* vmask = reinterpret_cast<unsigned long long*>(lds + L.valid);
+  double* aa = lds + L.lanec;
+  if (has_people) stage_people<W>(&k, scene, sl, ag, vmask, aa);
+  wave_lds_fence();
+  if (live && has_people) {
+    const size_t s = scene;
+    const int nrec = N * T;
+    v4d* dst = reinterpret_cast<v4d*>(k.stage_rec + s * (size_t)4 * nrec);
+    const v4d* src = reinterpret_cast<const v4d*>(ag);
+    for (int q = sl; q < nrec; q += W) dst[q] = src[q];  // consecutive lanes, consecutive 32-byte records
+    if (sl < T) {
+      double* aux = k.stage_aux + (s * T + sl) * 2;
+      aux[0] = (lds + L.valid)[sl];
+      aux[1] = aa[sl];
+    }
+  }
 }
 
 }  // namespace smpc

@@ -71,6 +71,10 @@ def load_library():
     lib.smpc_trajectorize_path_batch.restype = C.c_int
     lib.smpc_select_command_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
     lib.smpc_select_command_batch.restype = C.c_int
+    lib.smpc_stage_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.c_void_p]
+    lib.smpc_stage_people_batch.restype = C.c_int
+    lib.smpc_math_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
+    lib.smpc_math_probe.restype = C.c_int
     lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
     lib.smpc_last_kernel_ms.restype = C.c_double
     if lib.smpc_abi_version() != _abi.SMPC_ABI_VERSION:
@@ -109,6 +113,17 @@ class BatchSolver:
 
     def set_stream(self, stream_ptr: int):
         _check(self.lib, self.lib.smpc_set_stream(self._h, C.c_void_p(stream_ptr)), "smpc_set_stream")
+
+    def math_probe(self, fn: int, a: np.ndarray, b: np.ndarray = None):
+        """smpc_math_probe: the sweep's elementary functions evaluated on the device (see include/smpc.h)."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        n = a.size
+        bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        o0 = np.empty(n)
+        o1 = np.empty(n)
+        _check(self.lib, self.lib.smpc_math_probe(self._h, int(fn), n, a.ctypes.data, None if bb is None else bb.ctypes.data,
+                                                  o0.ctypes.data, o1.ctypes.data), "smpc_math_probe")
+        return o0, o1
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.smpc_last_kernel_ms(self._h))
@@ -333,6 +348,30 @@ class BatchSolver:
         for k, v in t.items():
             setattr(rb, k, v.data_ptr())
         return rb, t
+
+    def stage_people(self, scenes: SceneBatch):
+        """smpc_stage_people_batch on host arrays: (records [B,N,T,4], aux [B,T,2])."""
+        B, T, N = scenes.B, scenes.T, scenes.N
+        rec = np.zeros((B, N, T, 4))
+        aux = np.zeros((B, T, 2))
+        sb = scenes.to_c()
+        _check(self.lib, self.lib.smpc_stage_people_batch(self._h, C.byref(sb), rec.ctypes.data, aux.ctypes.data),
+               "smpc_stage_people_batch")
+        return rec, aux
+
+    def stage_people_device(self, sb: SmpcSceneBatch, device="cuda:0"):
+        """Stage the device-resident people block of `sb` once and attach the result to it: later solve_device /
+        eval_device calls with this batch read the staged records instead of running the staging pass again.
+        Returns the tensors that own the memory (keep them alive as long as `sb` is used)."""
+        import torch
+
+        assert sb.on_device == 1
+        rec = torch.zeros((sb.B, sb.N, sb.T, 4), dtype=torch.float64, device=device)
+        aux = torch.zeros((sb.B, sb.T, 2), dtype=torch.float64, device=device)
+        _check(self.lib, self.lib.smpc_stage_people_batch(self._h, C.byref(sb), C.c_void_p(rec.data_ptr()),
+                                                          C.c_void_p(aux.data_ptr())), "smpc_stage_people_batch")
+        sb.people_records, sb.people_aux = rec.data_ptr(), aux.data_ptr()
+        return rec, aux
 
     def solve_device(self, sb: SmpcSceneBatch, rb: SmpcResultBatch):
         assert sb.on_device == 1

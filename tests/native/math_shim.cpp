@@ -1,0 +1,20 @@
+// Host-side shim over csrc/smpc_math.hpp for tests/test_math.py: the same source the kernels compile, with the
+// hardware reciprocal / rsqrt estimates replaced by single-precision stand-ins (smpc_math.hpp, host branch).
+#include "../../nav2_social_mpc_controller_amd/csrc/smpc_math.hpp"
+
+extern "C" {
+void shim_exp(const double* x, double* o, int n) {
+  smpc::MathTab t; smpc::fill_math_table(&t);
+  for (int i = 0; i < n; ++i) o[i] = smpc::exp_tab(&t, x[i]);
+}
+void shim_atan2(const double* y, const double* x, double* o, int n) {
+  smpc::MathTab t; smpc::fill_math_table(&t);
+  for (int i = 0; i < n; ++i) o[i] = smpc::atan2_dir(&t, y[i], x[i]);
+}
+void shim_sincos(const double* x, double* s, double* c, int n) {
+  smpc::MathTab t; smpc::fill_math_table(&t);
+  for (int i = 0; i < n; ++i) smpc::sincos_tab(&t, x[i], &s[i], &c[i]);
+}
+void shim_rsqrt(const double* x, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = smpc::rsqrt_pos(x[i]); }
+void shim_div(const double* a, const double* b, double* o, int n) { for (int i = 0; i < n; ++i) o[i] = smpc::div_fast(a[i], b[i]); }
+}

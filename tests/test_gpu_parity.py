@@ -322,3 +322,51 @@ def test_non_finite_inputs_terminate_and_fail_cleanly(Solver):
     rest = np.setdiff1d(np.arange(64), hit)
     assert np.array_equal(out["status"][rest], clean["status"][rest])
     assert np.max(np.abs(out["cmds"][rest] - clean["cmds"][rest])) == 0.0
+
+
+def test_staged_people_block(Solver):
+    """smpc_stage_people_batch: the records / aux the sweep reads, against a numpy statement of the same conversion;
+    a solve and a sweep fed with the staged block give bit-identical results to the ones that stage internally."""
+    from nav2_social_mpc_controller_amd._abi import SmpcResultBatch, SmpcEvalOut
+    prm = README
+    sc = make_scenes(prm, 96, 5, seed=77, map_cells=80)
+    sc.people[3, :, 3, 2] = -1.0            # a phantom agent
+    sc.has_people[5] = 0
+    s = Solver(prm)
+    rec, aux = s.stage_people(sc)
+    T, N = sc.T, sc.N
+    ppl = sc.people[:, 1:]                  # people_proj[t + 1]
+    want = np.stack([ppl[:, :, 0], ppl[:, :, 1], ppl[:, :, 4] * np.cos(ppl[:, :, 2]), ppl[:, :, 4] * np.sin(ppl[:, :, 2])], axis=-1)
+    want = want.transpose(0, 2, 1, 3)       # [B][N][T][4]
+    live = sc.has_people != 0
+    assert np.abs(rec[live] - want[live]).max() <= 1e-15
+    mask = aux[..., 0].copy().view(np.uint64)
+    want_mask = ((ppl[:, :, 3] != -1.0) * (1 << np.arange(N))[None, None, :]).sum(axis=2).astype(np.uint64)
+    assert np.array_equal(mask[live], want_mask[live])
+    assert int(mask[3, 0]) & 4 == 0 and int(mask[2, 0]) & 4 == 4
+    tgt = aux[..., 1]
+    active = tgt != 1e300
+    assert active[live].any() and (~active[live]).any()
+    d = np.abs(np.abs(tgt - sc.pose0[:, None, 2]) - np.pi / 6)
+    assert d[active & live[:, None]].max() <= 1e-15
+    # same results with the caller-staged block (host pointers)
+    a = s.solve(sc)
+    ea = s.evaluate(sc, sc.init_params)
+    sb = sc.to_c()
+    sb.people_records, sb.people_aux = rec.ctypes.data, aux.ctypes.data
+    sb.people = None
+    CH, bl, nb, P, M, _ = prm.dims(T, True)
+    out = {"params": np.zeros((sc.B, P)), "cmds": np.zeros((sc.B, T + 1, 2)), "iterations": np.zeros(sc.B, np.int32)}
+    rb = SmpcResultBatch()
+    for k, v in out.items():
+        setattr(rb, k, v.ctypes.data)
+    import ctypes
+    assert s.lib.smpc_solve_batch(s._h, ctypes.byref(sb), ctypes.byref(rb)) == 0
+    for k in out:
+        assert np.array_equal(out[k], a[k]), k
+    J = np.zeros((sc.B, M, P))
+    eo = SmpcEvalOut()
+    eo.jacobian = J.ctypes.data
+    x = np.ascontiguousarray(sc.init_params)
+    assert s.lib.smpc_eval_batch(s._h, ctypes.byref(sb), x.ctypes.data, ctypes.byref(eo)) == 0
+    assert np.array_equal(J, ea["jacobian"])

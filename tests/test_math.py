@@ -1,0 +1,108 @@
+"""csrc/smpc_math.hpp on the host: the table-driven exp / atan2 / sincos and the refined reciprocal / rsqrt that the
+sweep uses instead of the device library, checked against libm (numpy) and against mpmath at 40 digits. The hardware
+estimates are replaced by single-precision stand-ins here; tests/test_gpu_math.py repeats the check on the device."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "math_shim.cpp")
+OUT = os.path.join(ROOT, "tests", "native", "_build", "libmath_shim.so")
+P = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def shim():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hdr = os.path.join(ROOT, "nav2_social_mpc_controller_amd", "csrc", "smpc_math.hpp")
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-o", OUT, SRC])
+    return ctypes.CDLL(OUT)
+
+
+def ptr(a):
+    return a.ctypes.data_as(P)
+
+
+def ulps(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    return np.abs(got - want) / np.spacing(np.abs(want))
+
+
+def mp_ulps(fn, got, xs):
+    """max error in ulps against a 40-digit evaluation, on a subsample"""
+    import mpmath as mp
+    mp.mp.dps = 40
+    worst = 0.0
+    for g, x in zip(got, xs):
+        ref = fn(*x) if isinstance(x, tuple) else fn(x)
+        u = abs(mp.mpf(float(g)) - ref) / mp.mpf(float(np.spacing(abs(float(ref))))) if ref != 0 else 0
+        worst = max(worst, float(u))
+    return worst
+
+
+def test_exp(shim):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([-rng.uniform(0, 60, 200000), -rng.uniform(0, 745, 50000), -10.0 ** rng.uniform(-20, 0, 20000),
+                        np.array([0.0, -0.0, -1e-300, -745.0, -746.0, -800.0, -1e300, -np.inf])])
+    o = np.empty_like(x)
+    shim.shim_exp(ptr(x), ptr(o), len(x))
+    want = np.exp(x)
+    normal = want > 1e-300
+    assert ulps(o[normal], want[normal]).max() <= 1.0
+    assert np.all(o[~normal] <= 1e-300) and np.all(o[~normal] >= 0.0)
+    import mpmath as mp
+    assert mp_ulps(mp.exp, o[:3000], [mp.mpf(float(v)) for v in x[:3000]]) <= 1.0
+
+
+def test_atan2_of_directions(shim):
+    rng = np.random.default_rng(2)
+    ang = np.concatenate([rng.uniform(-np.pi, np.pi, 300000), np.array([0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi, -np.pi / 2]),
+                          rng.choice([-1, 1], 20000) * 10.0 ** rng.uniform(-12, -1, 20000),
+                          np.pi - 10.0 ** rng.uniform(-12, -1, 20000)])
+    scale = 1.0 + 1e-15 * rng.standard_normal(len(ang))
+    y, x = np.sin(ang) * scale, np.cos(ang) * scale
+    o = np.empty_like(x)
+    shim.shim_atan2(ptr(y), ptr(x), ptr(o), len(x))
+    want = np.arctan2(y, x)
+    u = ulps(o, want)
+    # pi/2 - atan(t) drops the low-order part of pi/2 (6e-17): up to 2 ulps for results below 1, rarely
+    assert u.max() <= 2.0 and (u > 1.0).mean() < 1e-3
+    import mpmath as mp
+    assert mp_ulps(mp.atan2, o[:3000], [(mp.mpf(float(a)), mp.mpf(float(b))) for a, b in zip(y[:3000], x[:3000])]) <= 1.6
+    # non-unit lengths (a few orders of magnitude either way) are fine too
+    k = 10.0 ** rng.uniform(-3, 3, len(ang))
+    yk, xk = y * k, x * k
+    shim.shim_atan2(ptr(yk), ptr(xk), ptr(o), len(x))
+    assert ulps(o, np.arctan2(yk, xk)).max() <= 2.0
+
+
+def test_sincos(shim):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-20, 20, 300000), rng.uniform(-1e5, 1e5, 50000),
+                        np.arange(-40, 41) * (np.pi / 4), np.array([0.0, 1e-300, -1e-9])])
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    shim.shim_sincos(ptr(x), ptr(s), ptr(c), len(x))
+    # absolute accuracy is what the rollout needs (v cos(theta) dt): 1 ulp of 1, i.e. 2.3e-16, everywhere
+    assert np.abs(s - np.sin(x)).max() <= 2.3e-16
+    assert np.abs(c - np.cos(x)).max() <= 2.3e-16
+    small = np.abs(x) <= 20
+    away = small & (np.abs(np.sin(x)) > 1e-3) & (np.abs(np.cos(x)) > 1e-3)
+    assert ulps(s[away], np.sin(x[away])).max() <= 1.0
+    assert ulps(c[away], np.cos(x[away])).max() <= 1.0
+
+
+def test_rsqrt_and_division(shim):
+    rng = np.random.default_rng(4)
+    x = 10.0 ** rng.uniform(-12, 6, 300000)
+    o = np.empty_like(x)
+    shim.shim_rsqrt(ptr(x), ptr(o), len(x))
+    assert ulps(o, 1.0 / np.sqrt(x)).max() <= 2.0  # the comparison value carries an ulp of its own
+    a = rng.uniform(0, 1, 300000)
+    b = np.maximum(a, rng.uniform(0.5, 1, 300000))
+    shim.shim_div(ptr(a), ptr(b), ptr(o), len(x))
+    assert ulps(o[a > 0], (a / b)[a > 0]).max() <= 1.0

@@ -13,6 +13,7 @@ s = BatchSolver(prm)
 sb, tens = sc.to_device()
 rb, rt = s.alloc_results(B, sc.T)
 eo, et = s.alloc_eval(B, sc.T)
+keep = s.stage_people_device(sb)
 for _ in range(3):
     s.eval_device(sb, tens["init_params"].data_ptr(), eo)
 k1 = s.last_kernel_ms()

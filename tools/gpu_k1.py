@@ -13,6 +13,8 @@ for B, N in ((8192, 8), (32768, 8), (8192, 16), (8192, 0)):
     s = BatchSolver(p)
     sb, tens = sc.to_device()
     eo, et = s.alloc_eval(B, sc.T)
+    if N > 0:
+        keep = s.stage_people_device(sb)
     torch.cuda.synchronize()
     ms = []
     for i in range(12):

@@ -16,7 +16,16 @@ def bench(name, p, B, N, reps=3, **kw):
     torch.cuda.synchronize()
     for i in range(reps):
         s.eval_device(sb, tens["init_params"].data_ptr(), eo)
+        ms_raw = s.last_kernel_ms()
+    for i in range(reps):
+        s.solve_device(sb, rb)
+        ms_solve_raw = s.last_kernel_ms()
+    keep = s.stage_people_device(sb)          # from here on the batch carries its staged people block
+    stage_ms = s.last_kernel_ms()
+    for i in range(reps + 2):
+        s.eval_device(sb, tens["init_params"].data_ptr(), eo)
         ms = s.last_kernel_ms()
+    print(f"[{name}] staging pass {stage_ms*1e3:.1f} us; K1 kernel with library-side staging before it {ms_raw*1e3:.1f} us; solve kernel (raw people input) {ms_solve_raw:.3f} ms")
     bytes_sweep = 8 * (6 * N * sc.T + 2 * (sc.T + 1) + P + 5) + 16 * sc.T + 8 * (M * P + M)
     print(f"[{name}] K1 eval B={B}: {ms:.3f} ms -> {B/ms*1e3:.3e} scene-sweeps/s, {B*bytes_sweep/ms/1e6:.1f} GB/s algorithmic ({bytes_sweep} B/sweep)")
     for i in range(reps):
