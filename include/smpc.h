@@ -150,6 +150,12 @@ typedef struct smpc_eval_batch_out {
   double* jacobian;  /* [B][M][P] dense, unscaled */
   double* cost;      /* [B] 0.5*||r||^2 */
   double* gradient;  /* [B][P] J^T r */
+  /* Row order of residuals / jacobian. 0: the reference's (step-major, SURVEY §8 a10: per step i the critics in the
+   * order of src/optimizer.cpp:263-363, the feasibility row of block i behind step i). 1: critic-major — row of
+   * critic c at step i at index c * T + i (c = 0..7 with people, 0..4 without, same critic order), the feasibility
+   * rows behind them at rows_per_step * T + (block - 1): the same rows, laid out so that the T rows of one critic are
+   * one contiguous block that the kernel writes as whole 128-byte lines. */
+  int32_t row_order;
 } smpc_eval_batch_out;
 
 /* People projection that feeds the hot path: Optimizer::project_people + computeObstacle

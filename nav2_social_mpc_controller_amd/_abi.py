@@ -197,6 +197,7 @@ class SmpcEvalOut(C.Structure):
         ("jacobian", C.c_void_p),
         ("cost", C.c_void_p),
         ("gradient", C.c_void_p),
+        ("row_order", C.c_int32),
     ]
 
 

@@ -64,6 +64,7 @@ struct KParams {
   double* e_cost;
   double* e_gradient;
   int e_M;  // row stride of the eval outputs (M with people)
+  int e_row_order;  // 0: reference (step-major) row order, 1: critic-major (smpc_eval_batch_out.row_order)
   MathTab mt;  // polynomial coefficients of smpc_math.hpp, read through scalar loads
 };
 
@@ -424,6 +425,7 @@ struct GramView {
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 // Staging pass (its own kernel, once per people block): gather the slot's people block, agent index fastest across
 // lanes (coalesced runs of one people row, 16 loads in flight per lane), convert to one 32-byte record (px, py, vx, vy)
@@ -546,7 +548,11 @@ __device__ inline void load_scene(Ctx& c, int scene) {
 // reduced over the slot in every lane of the slot.
 // When out_r / out_J are non-null (stand-alone K1) the rows are also written to HBM in the reference order.
 // ------------------------------------------------------------------------------------------------
-template <int NB, int W>
+// kRows = false: the solve kernel's sweep, full Gram [J r]^T [J r] (MFMA back-end where it fits), nothing written.
+// kRows = true: the stand-alone K1 sweep; rows go to HBM, and of the Gram only its last column (J^T r and r^T r: the
+// gradient and the cost smpc_eval_batch reports) is accumulated, on the VALU — c.wave_lds is then the row staging
+// area of the critic-major store path (2 x T x P doubles per slot).
+template <int NB, int W, bool kRows>
 __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J) {
   constexpr int P = 2 * NB;
   const auto& k = *c.kp;
@@ -764,7 +770,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 
   SMPC_STAMP(c, 4);
   // ---- per-step rows: state-space gradients (gx, gy, gth) + direct dv on block myb, pushed into the Gram
-  constexpr bool kMfma = use_mfma(P, W);
+  constexpr bool kMfma = !kRows && use_mfma(P, W);
   constexpr int kCols = tile_cols(W);
   constexpr int Q = P + 1;
   const auto& w = k.prm;
@@ -773,9 +779,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   const int rows_per_step = people ? 8 : 5;
   const int row_base = rows_per_step * sl + min(max(sl - 1, 0), k.nfeas);
   Gram<P> gram;        // VALU back-end accumulators (dead code in the MFMA build)
+  double gcol[Q];      // kRows: last column of the Gram only
   v4d acc = {0.0, 0.0, 0.0, 0.0};  // MFMA back-end accumulators: C[(lane>>4) + 4 reg][lane & 15]
   double* tile = c.wave_lds;
   double* my_row = tile + c.slot * tile_slot_stride(W) + sl * kCols;
+  double* stage = c.wave_lds + c.slot * (2 * T * P);  // kRows: two row blocks of this slot, used alternately
+  const bool critic_major = kRows && k.e_row_order == 1;
   const double* rd_base;
   {
     const int lane = threadIdx.x & 63;
@@ -785,6 +794,9 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   if (kMfma) {
 #pragma unroll
     for (int q = Q; q < kCols; ++q) my_row[q] = 0.0;  // padding columns stay zero for the whole sweep
+  } else if (kRows) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) gcol[q] = 0.0;
   } else {
     gram.clear();
   }
@@ -803,23 +815,52 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
       for (int m = 0; m < kM; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], a[m], acc, 0, 0, 0);
       wave_lds_fence();
+    } else if (kRows) {
+      const double rl = live ? r : 0.0;
+#pragma unroll
+      for (int q = 0; q < P; ++q) gcol[q] = fma(live ? row[q] : 0.0, rl, gcol[q]);
+      gcol[P] = fma(rl, rl, gcol[P]);
     } else {
       if (live) gram.add_row(row, r);
     }
   };
-  auto emit = [&](int local, bool live, double r, double gx, double gy, double gth, double gv) {
+  auto emit = [&](int local, bool live, bool slot_on, double r, double gx, double gy, double gth, double gv) {
     double row[P];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       row[2 * q] = gx * Sxv[q] + gy * Syv[q] + ((q == myb) ? gv : 0.0);
       row[2 * q + 1] = gx * Sxw[q] + gy * Syw[q] + gth * Sthw[q];
     }
-    if (live) {
-      const int rowi = row_base + local;
-      if (out_r) out_r[rowi] = r;
-      if (out_J) {
+    if (kRows) {
+      if (critic_major) {
+        // Row (critic `local`, step sl) lives at index local * T + sl: the T rows of one critic are one contiguous
+        // block of T * P doubles. They pass through LDS so that every store instruction writes whole runs of
+        // consecutive 16-byte pieces (lane-strided 48-byte rows touch 64 different lines per instruction and leave
+        // partially written lines behind: measured 1.49 x write amplification in round 1).
+        double* blk = stage + (local & 1) * (T * P);
+        if (lane_live && slot_on) {
 #pragma unroll
-        for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
+          for (int q = 0; q < P; q += 2) {
+            v2d pr = {live ? row[q] : 0.0, live ? row[q + 1] : 0.0};
+            reinterpret_cast<v2d*>(blk + sl * P)[q >> 1] = pr;
+          }
+        }
+        wave_lds_fence();
+        if (out_J && slot_on) {
+          v2d* dst = reinterpret_cast<v2d*>(out_J + (size_t)local * T * P);
+          const v2d* src = reinterpret_cast<const v2d*>(blk);
+          for (int i = sl; i < T * NB; i += W) dst[i] = src[i];
+        }
+        if (out_r && lane_live && slot_on) out_r[local * T + sl] = r;
+        // no second fence: the next critic writes the other block, and the one after that comes behind this
+        // critic's reads in program order with a fence in between
+      } else if (live) {
+        const int rowi = row_base + local;
+        if (out_r) out_r[rowi] = r;
+        if (out_J) {
+#pragma unroll
+          for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
+        }
       }
     }
     push(row, r, live);
@@ -835,7 +876,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         r = w.agent_angle_w * (ad * ad);
         gth = w.agent_angle_w * 2.0 * ad;
       }
-      emit(0, live, r, 0.0, 0.0, gth, 0.0);
+      emit(0, live, people, r, 0.0, 0.0, gth, 0.0);
     }
     // a3 social work: w (|sum F|^2 + sum |G|^2 + 1e-6)
     {
@@ -845,7 +886,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       const double gy = w.socialwork_w * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
       const double gt = w.socialwork_w * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
       const double gv = w.socialwork_w * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
-      emit(1, live, r, gx, gy, gt, gv);
+      emit(1, live, people, r, gx, gy, gt, gv);
     }
     // a4 proxemics: w alpha exp(-min_a d^2 / d0^2) over valid agents
     {
@@ -857,7 +898,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         // (critics/proxemics_cost_function.hpp:127,147) -> Ceres rejects the evaluation. Mirror it.
         gx = gy = __longlong_as_double(0x7ff8000000000000ll);
       }
-      emit(2, live, r, gx, gy, 0.0, 0.0);
+      emit(2, live, people, r, gx, gy, 0.0, 0.0);
     }
   }
   SMPC_STAMP2(c, 0);  // people critics (agent angle, social combine, proxemics) + their pushes
@@ -866,22 +907,22 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   {
     double r = 0.0, gv = 0.0;
     if (sl < CH) { const double d = w.desired_linear_vel - vb; r = w.velocity_w * d * d; gv = -2.0 * w.velocity_w * d; }
-    emit(o5 + 0, lane_live, r, 0.0, 0.0, 0.0, gv);
+    emit(o5 + 0, lane_live, true, r, 0.0, 0.0, 0.0, gv);
   }
   // a8 goal align
   {
     const double a = wrap_angle(cst[3] - th1);
-    emit(o5 + 1, lane_live, w.goal_align_w * a * a, 0.0, 0.0, -2.0 * w.goal_align_w * a, 0.0);
+    emit(o5 + 1, lane_live, true, w.goal_align_w * a * a, 0.0, 0.0, -2.0 * w.goal_align_w * a, 0.0);
   }
   // a2 distance (path follow -> final point; path align -> point sl+1)
   {
     const double ddx = X - cst[6], ddy = Y - cst[7], q2 = ddx * ddx + ddy * ddy;
-    emit(o5 + 2, lane_live, w.distance_w * q2 * q2, 4.0 * w.distance_w * q2 * ddx, 4.0 * w.distance_w * q2 * ddy, 0.0, 0.0);
+    emit(o5 + 2, lane_live, true, w.distance_w * q2 * q2, 4.0 * w.distance_w * q2 * ddx, 4.0 * w.distance_w * q2 * ddy, 0.0, 0.0);
   }
   {
     const double* lanec = c.lds + c.L.lanec;
     const double ddx = X - lanec[tl], ddy = Y - lanec[T + tl], q2 = ddx * ddx + ddy * ddy;
-    emit(o5 + 3, lane_live, w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
+    emit(o5 + 3, lane_live, true, w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
   }
   SMPC_STAMP2(c, 1);  // velocity, goal, 2 x distance
   // a5 obstacle
@@ -893,7 +934,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     bicubic(c.map, k.size_x, k.size_y, ir, ic, f, dfdr, dfdc);
     const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
     const double gth = w.obstacle_w * (dfdc * (-0.25 * s1) + dfdr * (0.25 * c1)) * inv_res;
-    emit(o5 + 4, lane_live, w.obstacle_w * f, gx, gy, gth, 0.0);
+    emit(o5 + 4, lane_live, true, w.obstacle_w * f, gx, gy, gth, 0.0);
   }
   SMPC_STAMP2(c, 2);  // obstacle (bicubic gather)
   // a9 velocity feasibility between blocks sl and sl-1 (src/optimizer.cpp:364-370); the row follows step sl
@@ -914,8 +955,8 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         row[2 * q - 1] = -2.0 * w.velocity_feasibility_w * ang;
       }
     }
-    if (live) {
-      const int rowi = row_base + rows_per_step;
+    if (kRows && live) {
+      const int rowi = critic_major ? rows_per_step * T + (sl - 1) : row_base + rows_per_step;
       if (out_r) out_r[rowi] = r;
       if (out_J) {
 #pragma unroll
@@ -934,6 +975,16 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const int o = (W == 32) ? 8 * c.slot : 0;
     view.base = ctile + o * 16 + o;
     view.ld = 16;
+  } else if (kRows) {
+    double* gt = c.lds + c.L.gram;
+#pragma unroll
+    for (int a = 0; a < Q; ++a) {
+      const double v = slot_sum<W>(gcol[a]);
+      gt[a * Q + P] = v;
+      gt[P * Q + a] = v;
+    }
+    view.base = gt;
+    view.ld = Q;
   } else {
     double* gt = c.lds + c.L.gram;
 #pragma unroll

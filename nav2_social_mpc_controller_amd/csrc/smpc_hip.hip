@@ -241,7 +241,9 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   const int S = smpc::kWave / W;
   KernelFn fn = pick(k.nb, W, eval);
   const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve);
-  const size_t shmem = ((size_t)S * L.total + smpc::wave_extra_doubles(k.P, W)) * sizeof(double);
+  // behind the slot blocks: the MFMA row / result tiles (solve) or the two row staging blocks per slot (K1)
+  const size_t extra = eval ? (size_t)S * 2 * k.T * k.P : (size_t)smpc::wave_extra_doubles(k.P, W);
+  const size_t shmem = ((size_t)S * L.total + extra) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
   if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (k.B == 0) return SMPC_OK;
@@ -785,6 +787,7 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* pa
   Dims d;
   SMPC_TRY(validate(h, sb, &d));
   if (!out || !params) { set_error("null params / output"); return SMPC_ERR_INVALID_ARG; }
+  if (out->row_order != 0 && out->row_order != 1) { set_error("row_order must be 0 or 1"); return SMPC_ERR_INVALID_ARG; }
   SMPC_HIP_CHECK(hipSetDevice(h->device));
   smpc::KParams k;
   fill_kparams(h, sb, d, &k);
@@ -795,8 +798,10 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* pa
   if (sb->on_device) {
     k.e_x = params;
     k.e_residuals = out->residuals; k.e_jacobian = out->jacobian; k.e_cost = out->cost; k.e_gradient = out->gradient;
+    k.e_row_order = out->row_order;
     return launch(h, true, k);
   }
+  k.e_row_order = out->row_order;
   SMPC_TRY(st.up(params, B * d.P, &k.e_x, h->stream));
   SMPC_TRY(st.out(out->residuals, B * d.M, &k.e_residuals));
   SMPC_TRY(st.out(out->jacobian, B * d.M * d.P, &k.e_jacobian));

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     SMPC_STAMP(c, 0);  // fetch + load_scene
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
-    const GramView GH = sweep<NB, W>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    const GramView GH = sweep<NB, W, false>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
     const bool finite = gram_finite<P>(GH);
     const double val = 0.5 * GH(P, P);
     bool new_iteration = false;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
       if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)i * P + q] = 0.0;
     }
   }
-  const GramView G = sweep<NB, W>(c, k.e_x + s * P, out_r, out_J);
+  const GramView G = sweep<NB, W, true>(c, k.e_x + s * P, out_r, out_J);
   if (live && c.sl == 0 && k.e_cost) k.e_cost[s] = 0.5 * G(P, P);
   if (live && k.e_gradient && c.sl < P) k.e_gradient[s * P + c.sl] = G(c.sl, P);
 #ifdef SMPC_STAMPS

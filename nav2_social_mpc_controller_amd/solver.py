@@ -145,7 +145,21 @@ class BatchSolver:
         _check(self.lib, self.lib.smpc_solve_batch(self._h, C.byref(sb), C.byref(rb)), "smpc_solve_batch")
         return out
 
-    def evaluate(self, scenes: SceneBatch, x: np.ndarray):
+    def row_permutation(self, T: int, has_people: bool = True):
+        """perm with reference_rows = critic_major_rows[perm] (smpc_eval_batch_out.row_order 1 -> 0) for one scene."""
+        CH, bl, nb, P, M, _ = self.params.dims(T, has_people)
+        rps = 8 if has_people else 5
+        nfeas = M - rps * T
+        perm = np.empty(M, np.int64)
+        for t in range(T):
+            base = rps * t + min(max(t - 1, 0), nfeas)
+            for c in range(rps):
+                perm[base + c] = c * T + t
+            if 1 <= t <= nfeas:
+                perm[base + rps] = rps * T + (t - 1)
+        return perm
+
+    def evaluate(self, scenes: SceneBatch, x: np.ndarray, row_order: int = 0):
         CH, bl, nb, P, M, _ = self.params.dims(scenes.T, True)
         scenes.validate(P)
         B = scenes.B
@@ -156,6 +170,7 @@ class BatchSolver:
         eo = SmpcEvalOut()
         for k, v in out.items():
             setattr(eo, k, v.ctypes.data)
+        eo.row_order = int(row_order)
         sb = scenes.to_c()
         _check(self.lib, self.lib.smpc_eval_batch(self._h, C.byref(sb), x.ctypes.data, C.byref(eo)), "smpc_eval_batch")
         return out
@@ -377,7 +392,7 @@ class BatchSolver:
         assert sb.on_device == 1
         _check(self.lib, self.lib.smpc_solve_batch(self._h, C.byref(sb), C.byref(rb)), "smpc_solve_batch")
 
-    def alloc_eval(self, B: int, T: int, device="cuda:0"):
+    def alloc_eval(self, B: int, T: int, device="cuda:0", row_order: int = 0):
         import torch
 
         CH, bl, nb, P, M, _ = self.params.dims(T, True)
@@ -390,6 +405,7 @@ class BatchSolver:
         eo = SmpcEvalOut()
         for k, v in t.items():
             setattr(eo, k, v.data_ptr())
+        eo.row_order = int(row_order)
         return eo, t
 
     def eval_device(self, sb: SmpcSceneBatch, x_ptr: int, eo: SmpcEvalOut):

@@ -370,3 +370,25 @@ def test_staged_people_block(Solver):
     x = np.ascontiguousarray(sc.init_params)
     assert s.lib.smpc_eval_batch(s._h, ctypes.byref(sb), x.ctypes.data, ctypes.byref(eo)) == 0
     assert np.array_equal(J, ea["jacobian"])
+
+
+def test_critic_major_row_order(Solver):
+    """smpc_eval_batch_out.row_order = 1 (the coalesced store path of K1) holds the same rows as the reference order,
+    permuted as the header says; cost and gradient do not depend on the order. With and without people, with a phantom,
+    with the feasibility rows of P = 10, for both slot widths."""
+    for prm, N, T, kw in ((README, 8, None, {}), (README, 3, None, {"people_present": False}),
+                          (README.replace(control_horizon=30, max_time=2.0), 16, None, {}),
+                          (README.replace(control_horizon=20, parameter_block_length=4, max_time=2.0), 3, None, {})):
+        sc = make_scenes(prm, 70, N, seed=11, map_cells=80, **kw)
+        if sc.has_people.all():
+            sc.has_people[4] = 0
+        s = Solver(prm)
+        a = s.evaluate(sc, sc.init_params, row_order=0)
+        b = s.evaluate(sc, sc.init_params, row_order=1)
+        assert np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["gradient"], b["gradient"])
+        for i in range(sc.B):
+            hp = bool(sc.has_people[i]) and N > 0
+            perm = s.row_permutation(sc.T, hp)
+            assert np.array_equal(a["residuals"][i, :len(perm)], b["residuals"][i][perm]), i
+            assert np.array_equal(a["jacobian"][i, :len(perm)], b["jacobian"][i][perm]), i
+            assert not a["jacobian"][i, len(perm):].any() and not b["jacobian"][i, len(perm):].any()
