@@ -194,73 +194,6 @@ __device__ __attribute__((noinline)) double interpolate_step(const Sample& lower
 
 // ---- register-resident fast paths of the line-search interpolation (same algorithm as above, no LDS loops) ----
 
-// Full-pivot Gaussian elimination of an n x n system held in registers; pivot choice and operation order follow
-// fullpiv_solve() exactly (row-major scan, strict '>'), swaps are done with selects.
-template <int n>
-__device__ inline void fullpiv_solve_reg(double (&A)[n][n], double (&b)[n], double (&out)[n]) {
-  int perm[n];
-#pragma unroll
-  for (int i = 0; i < n; ++i) perm[i] = i;
-  bool alive = true;  // false once a zero pivot block is met (remaining rhs := 0)
-#pragma unroll
-  for (int kk = 0; kk < n; ++kk) {
-    int pr = kk, pc = kk;
-    double best = -1.0;
-#pragma unroll
-    for (int i = kk; i < n; ++i) {
-#pragma unroll
-      for (int j = kk; j < n; ++j) {
-        const double v = fabs(A[i][j]);
-        const bool better = v > best;
-        best = better ? v : best; pr = better ? i : pr; pc = better ? j : pc;
-      }
-    }
-    if (alive && best == 0.0) {
-      alive = false;
-#pragma unroll
-      for (int i = kk; i < n; ++i) b[i] = 0.0;
-    }
-    if (alive) {
-#pragma unroll
-      for (int i = kk + 1; i < n; ++i) {
-        const bool sw = (pr == i);
-#pragma unroll
-        for (int j = 0; j < n; ++j) { const double t = A[i][j]; A[i][j] = sw ? A[kk][j] : t; A[kk][j] = sw ? t : A[kk][j]; }
-        const double t = b[i]; b[i] = sw ? b[kk] : t; b[kk] = sw ? t : b[kk];
-      }
-#pragma unroll
-      for (int j = kk + 1; j < n; ++j) {
-        const bool sw = (pc == j);
-#pragma unroll
-        for (int i = 0; i < n; ++i) { const double t = A[i][j]; A[i][j] = sw ? A[i][kk] : t; A[i][kk] = sw ? t : A[i][kk]; }
-        const int t = perm[j]; perm[j] = sw ? perm[kk] : t; perm[kk] = sw ? t : perm[kk];
-      }
-#pragma unroll
-      for (int i = kk + 1; i < n; ++i) {
-        const double f = A[i][kk] / A[kk][kk];
-#pragma unroll
-        for (int j = kk; j < n; ++j) A[i][j] -= f * A[kk][j];
-        b[i] -= f * b[kk];
-      }
-    }
-  }
-  double z[n];
-#pragma unroll
-  for (int i = n - 1; i >= 0; --i) {
-    double v = b[i];
-#pragma unroll
-    for (int kk = i + 1; kk < n; ++kk) v -= A[i][kk] * z[kk];
-    z[i] = (A[i][i] == 0.0) ? 0.0 : v / A[i][i];
-  }
-#pragma unroll
-  for (int t = 0; t < n; ++t) out[t] = 0.0;
-#pragma unroll
-  for (int i = 0; i < n; ++i) {
-#pragma unroll
-    for (int t = 0; t < n; ++t) out[t] = (perm[i] == t) ? z[i] : out[t];
-  }
-}
-
 template <int nc> __device__ inline double eval_poly_reg(const double (&p)[nc], double x) {
   double v = 0.0;
 #pragma unroll
@@ -361,13 +294,14 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
   double opt_x = (lo + hi) / 2.0, opt_v;
   if (!use_prev) {
     constexpr int nc = 4;
-    // a x^3 + b x^2 = f1 - g0 x1 - f0 ;  3 a x^2 + 2 b x = g1 - g0   (2 x 2, full pivoting)
+    // a x1^3 + b x1^2 = f1 - g0 x1 - f0 =: A ;  3 a x1^2 + 2 b x1 = g1 - g0 =: B, solved in closed form (the reference
+    // runs a full-pivot LU on the 4 x 4 Vandermonde system: the same polynomial up to its round-off)
     const double x1 = current.x;
-    double A[2][2] = {{x1 * x1 * x1, x1 * x1}, {3.0 * (x1 * x1), 2.0 * x1}};
-    double b[2] = {current.value - g0 * x1 - f0, current.gradient - g0};
-    double ab[2];
-    fullpiv_solve_reg<2>(A, b, ab);
-    const double poly[nc] = {ab[0], ab[1], g0, f0};
+    if (x1 == 0.0) return false;
+    const double rx = fast_rcp(x1);
+    const double A = current.value - g0 * x1 - f0, Bx = (current.gradient - g0) * x1;
+    const double rxsq = rx * rx;
+    const double poly[nc] = {(Bx - 2.0 * A) * (rxsq * rx), (3.0 * A - Bx) * rxsq, g0, f0};
     opt_v = eval_poly_reg<nc>(poly, opt_x);
     const double vlo = eval_poly_reg<nc>(poly, lo);
     if (vlo < opt_v) { opt_v = vlo; opt_x = lo; }
@@ -394,21 +328,23 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
     return true;
   }
   constexpr int nc = 6;
-  double A[4][4], b[4], hi4[4];
-  const double xs[2] = {current.x, previous.x};
-  const double vs[2] = {current.value, previous.value};
-  const double gsv[2] = {current.gradient, previous.gradient};
-#pragma unroll
-  for (int smp = 0; smp < 2; ++smp) {
-    const double xv = xs[smp];
-    const double x2 = xv * xv, x3 = x2 * xv, x4 = x2 * x2, x5 = x4 * xv;
-    A[2 * smp][0] = x5; A[2 * smp][1] = x4; A[2 * smp][2] = x3; A[2 * smp][3] = x2;
-    A[2 * smp + 1][0] = 5.0 * x4; A[2 * smp + 1][1] = 4.0 * x3; A[2 * smp + 1][2] = 3.0 * x2; A[2 * smp + 1][3] = 2.0 * xv;
-    b[2 * smp] = vs[smp] - g0 * xv - f0;
-    b[2 * smp + 1] = gsv[smp] - g0;
-  }
-  fullpiv_solve_reg<4>(A, b, hi4);
-  const double poly[nc] = {hi4[0], hi4[1], hi4[2], hi4[3], g0, f0};
+  // Quintic through {0: f0, g0; x1 = current; x2 = previous}: Hermite divided differences on the nodes 0, 0, x1, x1, x2, x2
+  // and expansion of the Newton form. The reference solves the 6 x 6 Vandermonde system by full-pivot LU; against an
+  // exact solve the divided differences are the more accurate of the two (argmin within 3e-15 vs 8e-12 relative,
+  // tools/ — measured on 3000 random line searches), and they cost ~60 instructions instead of ~700 of select-based
+  // pivoting.
+  const double x1 = current.x, x2 = previous.x;
+  if (x1 == 0.0 || x2 == 0.0 || x1 == x2) return false;
+  const double r1 = fast_rcp(x1), r2 = fast_rcp(x2), r12 = fast_rcp(x2 - x1);
+  const double d01 = (current.value - f0) * r1, d12 = (previous.value - current.value) * r12;
+  const double e0 = (d01 - g0) * r1, e1 = (current.gradient - d01) * r1;
+  const double e2 = (d12 - current.gradient) * r12, e3 = (previous.gradient - d12) * r12;
+  const double h0 = (e1 - e0) * r1, h1 = (e2 - e1) * r2, h2 = (e3 - e2) * r12;
+  const double k0 = (h1 - h0) * r2, k1 = (h2 - h1) * r2;
+  const double m0 = (k1 - k0) * r2;
+  const double x1s = x1 * x1;
+  const double poly[nc] = {m0, k0 - m0 * (2.0 * x1 + x2), h0 - 2.0 * k0 * x1 + m0 * (x1s + 2.0 * x1 * x2),
+                           e0 - h0 * x1 + k0 * x1s - m0 * x1s * x2, g0, f0};
   double dq[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) dq[i] = (5 - i) * poly[i];

@@ -13,7 +13,8 @@ sc = make_scenes(p, B, N)
 s = BatchSolver(p)
 sb, tens = sc.to_device()
 rb, rt = s.alloc_results(B, sc.T)
-eo, et = s.alloc_eval(B, sc.T)
+eo, et = s.alloc_eval(B, sc.T, row_order=1)
+keep = s.stage_people_device(sb)   # K1 and the solve kernel read the staged people block
 for _ in range(3):
     s.eval_device(sb, tens["init_params"].data_ptr(), eo)
 for _ in range(nsolve):
