@@ -106,18 +106,14 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
 
 __host__ __device__ inline int slot_width(int T, int N) { return (T + 1 <= 32 && N <= 32) ? 32 : 64; }
 
-// Gram contraction back-end: MFMA f64 16x16x4 when [J r] (P+1 columns) of every slot of the wave fits the 16
-// columns of one tile (two 32-lane slots -> 8 columns each), else plain VALU accumulation + shuffle reduction.
-#ifdef SMPC_FORCE_VALU_GRAM
-__host__ __device__ constexpr bool use_mfma(int, int) { return false; }
-#else
-__host__ __device__ constexpr bool use_mfma(int P, int W) { return (W == 32) ? (P + 1 <= 8) : (P + 1 <= 16); }
-#endif
-__host__ __device__ constexpr int tile_cols(int W) { return (W == 32) ? 8 : 16; }
-__host__ __device__ constexpr int tile_slot_stride(int W) { return W * tile_cols(W) + ((W == 32) ? 16 : 0); }  // +32 dwords: bank shift
-// doubles of wave-shared LDS behind the per-slot blocks: row tile + 16x16 result tile
+// Cross-lane sum of the per-lane Gram shares (solve kernel): values go through LDS in chunks of whole columns of the
+// packed upper triangle, at most kGramChunk values at a time; lane j of a slot then adds up value j of every lane
+// (W additions instead of 3 log2(W) shuffle instructions per value).
+constexpr int kGramChunk = 16;
+__host__ __device__ constexpr int gram_red_doubles(int W) { return W * (kGramChunk + 1); }
+// doubles of wave-shared LDS behind the per-slot blocks of the solve kernel: reduction buffers + feasibility rows
 __host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
-  return use_mfma(P, W) ? (kWave / W) * tile_slot_stride(W) + 256 : 0;
+  return (kWave / W) * (gram_red_doubles(W) + (P / 2 > 1 ? P / 2 - 1 : 1) * (P + 1));
 }
 
 // The workgroup is ONE wavefront: LDS operations of a wave execute in program order, so cross-lane hand-offs through
@@ -393,28 +389,6 @@ struct Ctx {
   const double* ag;  // staged people records [N][T][4] of this slot's scene (global memory)
   double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
   LdsLayout L;
-};
-
-// Gram matrix [J r]^T [J r], packed upper triangle over P+1 columns (column P is r).
-template <int P> struct Gram {
-  static constexpr int Q = P + 1;
-  static constexpr int SZ = Q * (Q + 1) / 2;
-  double v[SZ];
-  __device__ static constexpr int idx(int a, int b) { return a * Q - a * (a - 1) / 2 + (b - a); }  // a <= b
-  __device__ inline void clear() {
-#pragma unroll
-    for (int i = 0; i < SZ; ++i) v[i] = 0.0;
-  }
-  __device__ inline void add_row(const double (&row)[P], double r) {
-#pragma unroll
-    for (int a = 0; a < P; ++a) {
-#pragma unroll
-      for (int b = a; b < P; ++b) v[idx(a, b)] = fma(row[a], row[b], v[idx(a, b)]);
-      v[idx(a, P)] = fma(row[a], r, v[idx(a, P)]);
-    }
-    v[idx(P, P)] = fma(r, r, v[idx(P, P)]);
-  }
-  __device__ inline double H(int a, int b) const { return a <= b ? v[idx(a, b)] : v[idx(b, a)]; }
 };
 
 // Dense symmetric view of the slot's Gram [J r]^T [J r] left in LDS by sweep(): G(a, b), a, b in 0..P (column P = r).
@@ -769,98 +743,71 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   }
 
   SMPC_STAMP(c, 4);
-  // ---- per-step rows: state-space gradients (gx, gy, gth) + direct dv on block myb, pushed into the Gram
-  constexpr bool kMfma = !kRows && use_mfma(P, W);
-  constexpr int kCols = tile_cols(W);
+  // ---- per-step critics: residual r and its state-space gradient (gx, gy, gth; gv = direct derivative with respect
+  // to the linear velocity of block myb). Row of the Jacobian = gradient x M, M = [S; selector] (4 x P), the same M
+  // for every critic of the step.
+  //   kRows (K1): the rows are formed and written to HBM; of the Gram only the last column is kept (VALU).
+  //   solve:      rows are never formed. Per lane A = sum_k g_k^T g_k (4 x 4), b = sum_k g_k r_k, cc = sum_k r_k^2 are
+  //               accumulated over the step's critics (most gradients have one to three non-zero components), then
+  //               the lane's share of [J r]^T [J r] is M^T A M, M^T b, cc — 1/3 of the multiply-adds of forming and
+  //               contracting eight P-wide rows, and no FP64 MFMA (on this part it runs at the FP64 VALU rate on the
+  //               same pipe: measured slower than plain VALU accumulation).
   constexpr int Q = P + 1;
   const auto& w = k.prm;
   const bool lane_live = sl < T;
   const bool people = c.has_people;
   const int rows_per_step = people ? 8 : 5;
   const int row_base = rows_per_step * sl + min(max(sl - 1, 0), k.nfeas);
-  Gram<P> gram;        // VALU back-end accumulators (dead code in the MFMA build)
   double gcol[Q];      // kRows: last column of the Gram only
-  v4d acc = {0.0, 0.0, 0.0, 0.0};  // MFMA back-end accumulators: C[(lane>>4) + 4 reg][lane & 15]
-  double* tile = c.wave_lds;
-  double* my_row = tile + c.slot * tile_slot_stride(W) + sl * kCols;
+  double Axx = 0.0, Axy = 0.0, Axt = 0.0, Axv = 0.0, Ayy = 0.0, Ayt = 0.0, Ayv = 0.0, Att = 0.0, Atv = 0.0, Avv = 0.0;
+  double bx = 0.0, by = 0.0, bt = 0.0, bv = 0.0, cc = 0.0;
   double* stage = c.wave_lds + c.slot * (2 * T * P);  // kRows: two row blocks of this slot, used alternately
   const bool critic_major = kRows && k.e_row_order == 1;
-  const double* rd_base;
-  {
-    const int lane = threadIdx.x & 63;
-    const int i = lane & 15, kq = lane >> 4;
-    rd_base = (W == 32) ? tile + (i >> 3) * tile_slot_stride(W) + kq * kCols + (i & 7) : tile + kq * kCols + i;
-  }
-  if (kMfma) {
-#pragma unroll
-    for (int q = Q; q < kCols; ++q) my_row[q] = 0.0;  // padding columns stay zero for the whole sweep
-  } else if (kRows) {
+  if (kRows) {
 #pragma unroll
     for (int q = 0; q < Q; ++q) gcol[q] = 0.0;
-  } else {
-    gram.clear();
   }
-  auto push = [&](const double (&row)[P], double r, bool live) {
-    if (kMfma) {
+  auto push = [&](const double (&row)[P], double r, bool live) {  // kRows only
+    const double rl = live ? r : 0.0;
 #pragma unroll
-      for (int q = 0; q < P; ++q) my_row[q] = live ? row[q] : 0.0;
-      my_row[P] = live ? r : 0.0;
-      wave_lds_fence();
-      // every lane of a slot writes its row (zeros beyond T), so all W/4 row groups are valid operands: issue the
-      // operand reads back to back, then the MFMA chain (an LDS round trip per MFMA would serialise ~200 cycles each)
-      constexpr int kM = W / 4;
-      double a[kM];
-#pragma unroll
-      for (int m = 0; m < kM; ++m) a[m] = rd_base[m * 4 * kCols];
-#pragma unroll
-      for (int m = 0; m < kM; ++m) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], a[m], acc, 0, 0, 0);
-      wave_lds_fence();
-    } else if (kRows) {
-      const double rl = live ? r : 0.0;
-#pragma unroll
-      for (int q = 0; q < P; ++q) gcol[q] = fma(live ? row[q] : 0.0, rl, gcol[q]);
-      gcol[P] = fma(rl, rl, gcol[P]);
-    } else {
-      if (live) gram.add_row(row, r);
-    }
+    for (int q = 0; q < P; ++q) gcol[q] = fma(live ? row[q] : 0.0, rl, gcol[q]);
+    gcol[P] = fma(rl, rl, gcol[P]);
   };
-  auto emit = [&](int local, bool live, bool slot_on, double r, double gx, double gy, double gth, double gv) {
+  auto emit = [&](int local, bool live, bool slot_on, double r, double gx, double gy, double gth, double gv) {  // kRows only
     double row[P];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       row[2 * q] = gx * Sxv[q] + gy * Syv[q] + ((q == myb) ? gv : 0.0);
       row[2 * q + 1] = gx * Sxw[q] + gy * Syw[q] + gth * Sthw[q];
     }
-    if (kRows) {
-      if (critic_major) {
-        // Row (critic `local`, step sl) lives at index local * T + sl: the T rows of one critic are one contiguous
-        // block of T * P doubles. They pass through LDS so that every store instruction writes whole runs of
-        // consecutive 16-byte pieces (lane-strided 48-byte rows touch 64 different lines per instruction and leave
-        // partially written lines behind: measured 1.49 x write amplification in round 1).
-        double* blk = stage + (local & 1) * (T * P);
-        if (lane_live && slot_on) {
+    if (critic_major) {
+      // Row (critic `local`, step sl) lives at index local * T + sl: the T rows of one critic are one contiguous
+      // block of T * P doubles. They pass through LDS so that every store instruction writes whole runs of
+      // consecutive 16-byte pieces (lane-strided 48-byte rows touch 64 different lines per instruction and leave
+      // partially written lines behind: measured 1.49 x write amplification in round 1).
+      double* blk = stage + (local & 1) * (T * P);
+      if (lane_live && slot_on) {
 #pragma unroll
-          for (int q = 0; q < P; q += 2) {
-            v2d pr = {live ? row[q] : 0.0, live ? row[q + 1] : 0.0};
-            reinterpret_cast<v2d*>(blk + sl * P)[q >> 1] = pr;
-          }
+        for (int q = 0; q < P; q += 2) {
+          v2d pr = {live ? row[q] : 0.0, live ? row[q + 1] : 0.0};
+          reinterpret_cast<v2d*>(blk + sl * P)[q >> 1] = pr;
         }
-        wave_lds_fence();
-        if (out_J && slot_on) {
-          v2d* dst = reinterpret_cast<v2d*>(out_J + (size_t)local * T * P);
-          const v2d* src = reinterpret_cast<const v2d*>(blk);
-          for (int i = sl; i < T * NB; i += W) dst[i] = src[i];
-        }
-        if (out_r && lane_live && slot_on) out_r[local * T + sl] = r;
-        // no second fence: the next critic writes the other block, and the one after that comes behind this
-        // critic's reads in program order with a fence in between
-      } else if (live) {
-        const int rowi = row_base + local;
-        if (out_r) out_r[rowi] = r;
-        if (out_J) {
+      }
+      wave_lds_fence();
+      if (out_J && slot_on) {
+        v2d* dst = reinterpret_cast<v2d*>(out_J + (size_t)local * T * P);
+        const v2d* src = reinterpret_cast<const v2d*>(blk);
+        for (int i = sl; i < T * NB; i += W) dst[i] = src[i];
+      }
+      if (out_r && lane_live && slot_on) out_r[local * T + sl] = r;
+      // no second fence: the next critic writes the other block, and the one after that comes behind this
+      // critic's reads in program order with a fence in between
+    } else if (live) {
+      const int rowi = row_base + local;
+      if (out_r) out_r[rowi] = r;
+      if (out_J) {
 #pragma unroll
-          for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
-        }
+        for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
       }
     }
     push(row, r, live);
@@ -876,53 +823,82 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         r = w.agent_angle_w * (ad * ad);
         gth = w.agent_angle_w * 2.0 * ad;
       }
-      emit(0, live, people, r, 0.0, 0.0, gth, 0.0);
+      if (kRows) emit(0, live, people, r, 0.0, 0.0, gth, 0.0);
+      else {
+        r = people ? r : 0.0; gth = people ? gth : 0.0;  // a slot without people beside one with people
+        Att = fma(gth, gth, Att); bt = fma(gth, r, bt); cc = fma(r, r, cc);
+      }
     }
     // a3 social work: w (|sum F|^2 + sum |G|^2 + 1e-6)
     {
       const double wr = soc[0] * soc[0] + soc[1] * soc[1];
-      const double r = w.socialwork_w * (wr + soc[10] + 1e-6);
-      const double gx = w.socialwork_w * (2.0 * (soc[0] * soc[2] + soc[1] * soc[3]) + soc[11]);
-      const double gy = w.socialwork_w * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
-      const double gt = w.socialwork_w * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
-      const double gv = w.socialwork_w * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
-      emit(1, live, people, r, gx, gy, gt, gv);
+      double r = w.socialwork_w * (wr + soc[10] + 1e-6);
+      double gx = w.socialwork_w * (2.0 * (soc[0] * soc[2] + soc[1] * soc[3]) + soc[11]);
+      double gy = w.socialwork_w * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
+      double gt = w.socialwork_w * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
+      double gv = w.socialwork_w * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
+      if (kRows) emit(1, live, people, r, gx, gy, gt, gv);
+      else {
+        r = people ? r : 0.0; gx = people ? gx : 0.0; gy = people ? gy : 0.0; gt = people ? gt : 0.0; gv = people ? gv : 0.0;
+        Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Axt = fma(gx, gt, Axt); Axv = fma(gx, gv, Axv);
+        Ayy = fma(gy, gy, Ayy); Ayt = fma(gy, gt, Ayt); Ayv = fma(gy, gv, Ayv);
+        Att = fma(gt, gt, Att); Atv = fma(gt, gv, Atv); Avv = fma(gv, gv, Avv);
+        bx = fma(gx, r, bx); by = fma(gy, r, by); bt = fma(gt, r, bt); bv = fma(gv, r, bv); cc = fma(r, r, cc);
+      }
     }
     // a4 proxemics: w alpha exp(-min_a d^2 / d0^2) over valid agents
     {
       const double e = 3.0 * exp_tab(&k.mt, -pbest / (0.5 * 0.5));
-      const double r = w.proxemics_w * e;
+      double r = w.proxemics_w * e;
       double gx = r * (-2.0 * pdx / (0.5 * 0.5)), gy = r * (-2.0 * pdy / (0.5 * 0.5));
       if (pbest == 1.7976931348623157e308) {
         // no valid agent: the reference's dual evaluation gives (-max / d0^2) = -inf and inf * 0 = NaN tangents
         // (critics/proxemics_cost_function.hpp:127,147) -> Ceres rejects the evaluation. Mirror it.
         gx = gy = __longlong_as_double(0x7ff8000000000000ll);
       }
-      emit(2, live, people, r, gx, gy, 0.0, 0.0);
+      if (kRows) emit(2, live, people, r, gx, gy, 0.0, 0.0);
+      else {
+        r = people ? r : 0.0; gx = people ? gx : 0.0; gy = people ? gy : 0.0;
+        Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Ayy = fma(gy, gy, Ayy);
+        bx = fma(gx, r, bx); by = fma(gy, r, by); cc = fma(r, r, cc);
+      }
     }
   }
-  SMPC_STAMP2(c, 0);  // people critics (agent angle, social combine, proxemics) + their pushes
+  SMPC_STAMP2(c, 0);  // people critics (agent angle, social combine, proxemics)
   const int o5 = people ? 3 : 0;
   // a6 velocity
   {
     double r = 0.0, gv = 0.0;
     if (sl < CH) { const double d = w.desired_linear_vel - vb; r = w.velocity_w * d * d; gv = -2.0 * w.velocity_w * d; }
-    emit(o5 + 0, lane_live, true, r, 0.0, 0.0, 0.0, gv);
+    if (kRows) emit(o5 + 0, lane_live, true, r, 0.0, 0.0, 0.0, gv);
+    else { Avv = fma(gv, gv, Avv); bv = fma(gv, r, bv); cc = fma(r, r, cc); }
   }
   // a8 goal align
   {
     const double a = wrap_angle(cst[3] - th1);
-    emit(o5 + 1, lane_live, true, w.goal_align_w * a * a, 0.0, 0.0, -2.0 * w.goal_align_w * a, 0.0);
+    const double r = w.goal_align_w * a * a, gth = -2.0 * w.goal_align_w * a;
+    if (kRows) emit(o5 + 1, lane_live, true, r, 0.0, 0.0, gth, 0.0);
+    else { Att = fma(gth, gth, Att); bt = fma(gth, r, bt); cc = fma(r, r, cc); }
   }
   // a2 distance (path follow -> final point; path align -> point sl+1)
   {
     const double ddx = X - cst[6], ddy = Y - cst[7], q2 = ddx * ddx + ddy * ddy;
-    emit(o5 + 2, lane_live, true, w.distance_w * q2 * q2, 4.0 * w.distance_w * q2 * ddx, 4.0 * w.distance_w * q2 * ddy, 0.0, 0.0);
+    const double r = w.distance_w * q2 * q2, gx = 4.0 * w.distance_w * q2 * ddx, gy = 4.0 * w.distance_w * q2 * ddy;
+    if (kRows) emit(o5 + 2, lane_live, true, r, gx, gy, 0.0, 0.0);
+    else {
+      Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Ayy = fma(gy, gy, Ayy);
+      bx = fma(gx, r, bx); by = fma(gy, r, by); cc = fma(r, r, cc);
+    }
   }
   {
     const double* lanec = c.lds + c.L.lanec;
     const double ddx = X - lanec[tl], ddy = Y - lanec[T + tl], q2 = ddx * ddx + ddy * ddy;
-    emit(o5 + 3, lane_live, true, w.angle_w * q2 * q2, 4.0 * w.angle_w * q2 * ddx, 4.0 * w.angle_w * q2 * ddy, 0.0, 0.0);
+    const double r = w.angle_w * q2 * q2, gx = 4.0 * w.angle_w * q2 * ddx, gy = 4.0 * w.angle_w * q2 * ddy;
+    if (kRows) emit(o5 + 3, lane_live, true, r, gx, gy, 0.0, 0.0);
+    else {
+      Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Ayy = fma(gy, gy, Ayy);
+      bx = fma(gx, r, bx); by = fma(gy, r, by); cc = fma(r, r, cc);
+    }
   }
   SMPC_STAMP2(c, 1);  // velocity, goal, 2 x distance
   // a5 obstacle
@@ -932,72 +908,135 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const double ic = (fxp - cst[4]) / k.resolution, ir = (fyp - cst[5]) / k.resolution;
     double f, dfdr, dfdc;
     bicubic(c.map, k.size_x, k.size_y, ir, ic, f, dfdr, dfdc);
+    const double r = w.obstacle_w * f;
     const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
     const double gth = w.obstacle_w * (dfdc * (-0.25 * s1) + dfdr * (0.25 * c1)) * inv_res;
-    emit(o5 + 4, lane_live, true, w.obstacle_w * f, gx, gy, gth, 0.0);
+    if (kRows) emit(o5 + 4, lane_live, true, r, gx, gy, gth, 0.0);
+    else {
+      Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Axt = fma(gx, gth, Axt);
+      Ayy = fma(gy, gy, Ayy); Ayt = fma(gy, gth, Ayt); Att = fma(gth, gth, Att);
+      bx = fma(gx, r, bx); by = fma(gy, r, by); bt = fma(gth, r, bt); cc = fma(r, r, cc);
+    }
   }
   SMPC_STAMP2(c, 2);  // obstacle (bicubic gather)
-  // a9 velocity feasibility between blocks sl and sl-1 (src/optimizer.cpp:364-370); the row follows step sl
-  if (k.nfeas > 0) {
-    const bool live = lane_live && sl >= 1 && sl <= k.nfeas;
-    double row[P];
-#pragma unroll
-    for (int q = 0; q < P; ++q) row[q] = 0.0;
-    double r = 0.0;
-#pragma unroll
-    for (int q = 1; q < NB; ++q) {
-      if (q == sl) {
-        const double lin = xp[2 * q] - xp[2 * q - 2], ang = xp[2 * q + 1] - xp[2 * q - 1];
-        r = w.velocity_feasibility_w * lin * lin + w.velocity_feasibility_w * ang * ang;
-        row[2 * q] = 2.0 * w.velocity_feasibility_w * lin;
-        row[2 * q - 2] = -2.0 * w.velocity_feasibility_w * lin;
-        row[2 * q + 1] = 2.0 * w.velocity_feasibility_w * ang;
-        row[2 * q - 1] = -2.0 * w.velocity_feasibility_w * ang;
-      }
-    }
-    if (kRows && live) {
-      const int rowi = critic_major ? rows_per_step * T + (sl - 1) : row_base + rows_per_step;
-      if (out_r) out_r[rowi] = r;
-      if (out_J) {
-#pragma unroll
-        for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
-      }
-    }
-    push(row, r, live);
-  }
-  // ---- hand the slot's Gram back through LDS
   GramView view;
-  if (kMfma) {
-    double* ctile = tile + (kWave / W) * tile_slot_stride(W);
-    const int lane = threadIdx.x & 63;
+  double* gt = c.lds + c.L.gram;
+  view.base = gt;
+  view.ld = Q;
+  if (kRows) {
+    // a9 velocity feasibility between blocks sl and sl-1 (src/optimizer.cpp:364-370); the row follows step sl
+    if (k.nfeas > 0) {
+      const bool live = lane_live && sl >= 1 && sl <= k.nfeas;
+      double row[P];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) ctile[((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
-    const int o = (W == 32) ? 8 * c.slot : 0;
-    view.base = ctile + o * 16 + o;
-    view.ld = 16;
-  } else if (kRows) {
-    double* gt = c.lds + c.L.gram;
+      for (int q = 0; q < P; ++q) row[q] = 0.0;
+      double r = 0.0;
+#pragma unroll
+      for (int q = 1; q < NB; ++q) {
+        if (q == sl) {
+          const double lin = xp[2 * q] - xp[2 * q - 2], ang = xp[2 * q + 1] - xp[2 * q - 1];
+          r = w.velocity_feasibility_w * lin * lin + w.velocity_feasibility_w * ang * ang;
+          row[2 * q] = 2.0 * w.velocity_feasibility_w * lin;
+          row[2 * q - 2] = -2.0 * w.velocity_feasibility_w * lin;
+          row[2 * q + 1] = 2.0 * w.velocity_feasibility_w * ang;
+          row[2 * q - 1] = -2.0 * w.velocity_feasibility_w * ang;
+        }
+      }
+      if (live) {
+        const int rowi = critic_major ? rows_per_step * T + (sl - 1) : row_base + rows_per_step;
+        if (out_r) out_r[rowi] = r;
+        if (out_J) {
+#pragma unroll
+          for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
+        }
+      }
+      push(row, r, live);
+    }
 #pragma unroll
     for (int a = 0; a < Q; ++a) {
       const double v = slot_sum<W>(gcol[a]);
       gt[a * Q + P] = v;
       gt[P * Q + a] = v;
     }
-    view.base = gt;
-    view.ld = Q;
   } else {
-    double* gt = c.lds + c.L.gram;
+    // ---- the lane's share of the Gram: H = M^T A M, g = M^T b, cc; summed over the slot's lanes through LDS.
+    if (!lane_live) {  // lanes beyond the horizon carry nothing (their A may hold anything, NaN included)
+      Axx = Axy = Axt = Axv = Ayy = Ayt = Ayv = Att = Atv = Avv = 0.0;
+      bx = by = bt = bv = cc = 0.0;
+    }
+    // a9 velocity feasibility rows (src/optimizer.cpp:364-370): row q (between blocks q and q-1, 1 <= q <= nfeas) has
+    // four non-zero entries; the rows go to LDS as they are and their outer products are added after the lane sum.
+    double* frow = c.wave_lds + (kWave / W) * gram_red_doubles(W) + c.slot * ((NB > 1 ? NB - 1 : 1) * Q);
+    if (sl >= 1 && sl <= k.nfeas) {
+      const double lin = xp[2 * sl] - xp[2 * sl - 2], ang = xp[2 * sl + 1] - xp[2 * sl - 1];
+      const double wf = w.velocity_feasibility_w;
+      double* fr = frow + (sl - 1) * Q;
 #pragma unroll
-    for (int a = 0; a < Q; ++a) {
+      for (int q = 0; q < Q; ++q) fr[q] = 0.0;
+      fr[2 * sl - 2] = -2.0 * wf * lin; fr[2 * sl - 1] = -2.0 * wf * ang;
+      fr[2 * sl] = 2.0 * wf * lin; fr[2 * sl + 1] = 2.0 * wf * ang;
+      fr[P] = wf * lin * lin + wf * ang * ang;
+    }
+    double* red = c.wave_lds + c.slot * gram_red_doubles(W) + sl * (kGramChunk + 1);
+    const double* red_col = c.wave_lds + c.slot * gram_red_doubles(W) + sl;
+    double hv[kGramChunk];
+    int cnt = 0, chunk_base = 0;  // compile-time after unrolling
+    auto flush = [&](int n, int base, int col_lo, int col_hi) {
+      wave_lds_fence();  // the previous chunk's sums have been read
 #pragma unroll
-      for (int b = a; b < Q; ++b) {
-        const double v = slot_sum<W>(gram.v[Gram<P>::idx(a, b)]);
-        gt[a * Q + b] = v;
-        gt[b * Q + a] = v;
+      for (int i = 0; i < kGramChunk; ++i) if (i < n) red[i] = hv[i];
+      wave_lds_fence();
+      if (sl < n) {
+        double tot = 0.0;
+#pragma unroll 8
+        for (int l = 0; l < W; ++l) tot += red_col[l * (kGramChunk + 1)];
+        // packed (column-major upper triangle) index -> (a, b)
+        const int pidx = base + sl;
+        int bcol = col_lo;
+#pragma unroll
+        for (int cb = 1; cb < Q; ++cb) if (cb > col_lo && cb <= col_hi) bcol = (pidx >= cb * (cb + 1) / 2) ? cb : bcol;
+        const int arow = pidx - bcol * (bcol + 1) / 2;
+        for (int q = 0; q < k.nfeas; ++q) tot = fma(frow[q * Q + arow], frow[q * Q + bcol], tot);
+        gt[arow * Q + bcol] = tot;
+        gt[bcol * Q + arow] = tot;
+      }
+    };
+    int col_lo = 0;
+#pragma unroll
+    for (int bq = 0; bq < Q; ++bq) {  // column bq of [J r]: 2q = v_q, 2q+1 = w_q, P = r
+      if (cnt + bq + 1 > kGramChunk) { flush(cnt, chunk_base, col_lo, bq - 1); chunk_base += cnt; cnt = 0; col_lo = bq; }
+      double Wx, Wy, Wt, Wv;  // column bq of A M (for bq = P: b itself)
+      if (bq == P) { Wx = bx; Wy = by; Wt = bt; Wv = bv; }
+      else if ((bq & 1) == 0) {
+        const int q = bq >> 1;
+        const double mq = (q == myb) ? 1.0 : 0.0;
+        Wx = fma(Axx, Sxv[q], fma(Axy, Syv[q], Axv * mq));
+        Wy = fma(Axy, Sxv[q], fma(Ayy, Syv[q], Ayv * mq));
+        Wt = fma(Axt, Sxv[q], fma(Ayt, Syv[q], Atv * mq));
+        Wv = fma(Axv, Sxv[q], fma(Ayv, Syv[q], Avv * mq));
+      } else {
+        const int q = bq >> 1;
+        Wx = fma(Axx, Sxw[q], fma(Axy, Syw[q], Axt * Sthw[q]));
+        Wy = fma(Axy, Sxw[q], fma(Ayy, Syw[q], Ayt * Sthw[q]));
+        Wt = fma(Axt, Sxw[q], fma(Ayt, Syw[q], Att * Sthw[q]));
+        Wv = fma(Axv, Sxw[q], fma(Ayv, Syw[q], Atv * Sthw[q]));
+      }
+#pragma unroll
+      for (int aq = 0; aq <= bq; ++aq) {
+        double h;
+        if (aq == P) h = cc;
+        else if ((aq & 1) == 0) {
+          const int q = aq >> 1;
+          const double mq = (q == myb) ? 1.0 : 0.0;
+          h = fma(Sxv[q], Wx, fma(Syv[q], Wy, mq * Wv));
+        } else {
+          const int q = aq >> 1;
+          h = fma(Sxw[q], Wx, fma(Syw[q], Wy, Sthw[q] * Wt));
+        }
+        hv[cnt++] = h;
       }
     }
-    view.base = gt;
-    view.ld = Q;
+    flush(cnt, chunk_base, col_lo, P);
   }
   wave_lds_fence();  // Gram visible to every lane of the slot; the cos/sin block may be rewritten by the next sweep
   SMPC_STAMP(c, 5);
