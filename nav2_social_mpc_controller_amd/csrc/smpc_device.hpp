@@ -74,7 +74,7 @@ struct LdsLayout {
                 //            records from global memory (HBM once in K1, L2 on the later sweeps of a solve)
   int valid;    // [T]        bit a set = agent a valid at step t (64-bit words)
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
-  int inc;      // [2][T]     per-step position increments of the current sweep
+  int inc;      // [4][T+1]   inclusive scans over j of cos, sin, j cos, j sin(theta_j) of the current sweep
   int cst;      // [8]        x0, y0, yaw0, goal_yaw, origin x, origin y, final point x, y
   int lanec;    // [3][T]     per step: path point x, y (path_pts[t+1]) and agent-angle target (kNoTarget = none)
   int lm;       // LM vectors / matrices / scalars
@@ -94,7 +94,7 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
   L.ag = o; if (kind == kLayoutStage) o += 4 * T * (N > 0 ? N : 1);
   L.valid = o; o += T;
   L.cs = o; o += 2 * (T + 1);
-  L.inc = o; o += 2 * T;
+  L.inc = o; o += 4 * (T + 1);
   L.cst = o; o += 8;
   L.lanec = o; o += 3 * T;
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;
@@ -546,51 +546,54 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   v4d rec0 = {0.0, 0.0, 0.0, 0.0}, rec1 = {0.0, 0.0, 0.0, 0.0};
   if (c.has_people) { rec0 = agr[0]; rec1 = agr[(N > 1 ? 1 : 0) * T]; }
 
-  // ---- a1 rollout, block-structured. theta_sl by sequential adds in the reference's order (:46-61).
+  // ---- a1 rollout (update_state.hpp:37-63), block-structured. The recurrences are sums, so they are evaluated as
+  // sums: theta_t = yaw0 + sum_b (w_b dt) * (steps of block b before t), and the positions through inclusive prefix
+  // sums over the lanes, restarted at every block boundary, of cos / sin(theta_j) and (j - block start) cos / sin:
+  // every partial sum the pose and its sensitivities need is then one scan entry (the lane's own for its block, the
+  // entry of a block's last step for the blocks before it) — no differences of long sums. (The reference adds the
+  // terms one step at a time; the orders differ by rounding only, a few ulp.)
   double th = cst[2];
-  {
-    int j = 0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int end = (b == NB - 1) ? T : (b + 1) * bl;
-      const double wdt = xp[2 * b + 1] * dt;
-      // (j < sl ? 1 : 0) * wdt added with one fma: the product with 1.0 is exact, so the sum is the reference's, and the
-      // 0 / 1 mask costs one 32-bit select (only the high words of 0.0 and 1.0 differ) instead of a 64-bit one
-      for (; j < end; ++j) th = fma((j < sl) ? 1.0 : 0.0, wdt, th);
-    }
+  for (int b = 0; b < NB; ++b) {
+    const int start = b * bl;
+    const int len = ((b == NB - 1) ? T : (b + 1) * bl) - start;
+    const int cnt = min(max(sl - start, 0), len);  // steps j < sl that block b drives
+    th = fma(xp[2 * b + 1] * dt, (double)cnt, th);
   }
+  const double th1 = th + wb * dt;  // theta_{sl+1}
+  double* scan_ = c.lds + c.L.inc;  // [4][T+1]: block-wise inclusive scans C, S, JC, JS over j = 0..T
+  const int seg_start = myb * bl;
   {
     double sn, cs;
     // headings of a rollout are modest numbers; the library routine (Payne-Hanek reduction) only for a lane that holds a
     // heading beyond the two-part Cody-Waite range (an unbounded last parameter block can produce one)
     if (__builtin_expect(!(fabs(th) <= 1e5), 0)) sincos(th, &sn, &cs);
     else sincos_tab(&k.mt, th, &sn, &cs);
-    if (sl <= T) { cs_[sl] = cs; sn_[sl] = sn; }
+    const double fj = (double)(sl - seg_start);
+    double sC = cs, sS = sn, sJC = fj * cs, sJS = fj * sn;
+#pragma unroll
+    for (int off = 1; off < W; off <<= 1) {
+      const double uC = __shfl_up(sC, off, W), uS = __shfl_up(sS, off, W);
+      const double uJC = __shfl_up(sJC, off, W), uJS = __shfl_up(sJS, off, W);
+      const double m = (sl - off >= seg_start) ? 1.0 : 0.0;  // the source lane belongs to this lane's block
+      sC = fma(m, uC, sC); sS = fma(m, uS, sS); sJC = fma(m, uJC, sJC); sJS = fma(m, uJS, sJS);
+    }
+    if (sl <= T) {
+      cs_[sl] = cs; sn_[sl] = sn;
+      scan_[sl] = sC; scan_[(T + 1) + sl] = sS; scan_[2 * (T + 1) + sl] = sJC; scan_[3 * (T + 1) + sl] = sJS;
+    }
   }
-  const double th1 = th + wb * dt;  // theta_{sl+1}: the same add the reference performs at step sl
   wave_lds_fence();
   SMPC_STAMP(c, 1);
-  // x, y of pose_{sl+1}: sequential sums over j <= sl in the reference's order. Lane j first publishes its own
-  // increments v_b(j) cos(theta_j) dt / v_b(j) sin(theta_j) dt (computed exactly as the reference rounds them),
-  // then every lane adds them up in index order, 8 LDS reads in flight at a time.
-  double* px_ = c.lds + c.L.inc;
-  double* py_ = px_ + T;
-  if (sl < T) {
-    px_[sl] = vb * cs_[sl] * dt;
-    py_[sl] = vb * sn_[sl] * dt;
-  }
-  wave_lds_fence();
+  // x, y of pose_{sl+1} = pose0 + sum_b v_b dt * (sum of cos / sin(theta_j) over the steps j <= sl of block b)
   double X = cst[0], Y = cst[1];
-  {
-    int j = 0;
-    for (; j + 8 <= T; j += 8) {
-      double ax[8], ay[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { ax[u] = px_[j + u]; ay[u] = py_[j + u]; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const double m = ((j + u) <= sl) ? 1.0 : 0.0; X = fma(m, ax[u], X); Y = fma(m, ay[u], Y); }
-    }
-    for (; j < T; ++j) { const double m = (j <= sl) ? 1.0 : 0.0; X = fma(m, px_[j], X); Y = fma(m, py_[j], Y); }
+  for (int b = 0; b < NB; ++b) {
+    const int end = (b == NB - 1) ? T : (b + 1) * bl;
+    const int idx = (b < myb) ? end - 1 : tl;   // a finished block: its last step; the lane's own block: the lane
+    const double m = (b <= myb) ? 1.0 : 0.0;
+    const double vdt = xp[2 * b] * dt * m;
+    X = fma(vdt, scan_[idx], X); Y = fma(vdt, scan_[(T + 1) + idx], Y);
   }
   const int t1 = min(sl + 1, T);
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
@@ -694,52 +697,29 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   }
 
   SMPC_STAMP(c, 3);
-  // ---- sensitivities S of pose_{sl+1} (after the agent loop: keeps them out of its register budget)
+  // ---- sensitivities S of pose_{sl+1} (after the agent loop: keeps them out of its register budget), from the scans
   double Sxv[NB], Syv[NB], Sxw[NB], Syw[NB], Sthw[NB];
-  {
-    int j = 0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int start = b * bl;
-      const int end = (b == NB - 1) ? T : (b + 1) * bl;
-      const double vdt = xp[2 * b] * dt;
-      double aC = 0.0, aS = 0.0, aJC = 0.0, aJS = 0.0;
-      for (; j + 4 <= end; j += 4) {  // 8 LDS reads in flight per trip
-        double cj[4], sj[4];
+  for (int b = 0; b < NB; ++b) {
+    const int start = b * bl;
+    const int end = (b == NB - 1) ? T : (b + 1) * bl;
+    const int idx = (b < myb) ? end - 1 : tl;
+    const double m = (b <= myb) ? 1.0 : 0.0;
+    const double aC = m * scan_[idx], aS = m * scan_[(T + 1) + idx];
+    const double aJC = m * scan_[2 * (T + 1) + idx], aJS = m * scan_[3 * (T + 1) + idx];  // sums of (j - start) cos / sin
+    const double vdt = xp[2 * b] * dt;
+    Sxv[b] = dt * aC;
+    Syv[b] = dt * aS;
+    // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
+    Sxw[b] = -vdt * dt * aJS;
+    Syw[b] = vdt * dt * aJC;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { cj[u] = cs_[j + u]; sj[u] = sn_[j + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool on = (j + u) <= sl;
-          const double m = on ? 1.0 : 0.0, mk = on ? (double)(j + u - start) : 0.0;  // masks: one 32-bit select each
-          aC = fma(m, cj[u], aC);
-          aS = fma(m, sj[u], aS);
-          aJC = fma(mk, cj[u], aJC);
-          aJS = fma(mk, sj[u], aJS);
-        }
-      }
-      for (; j < end; ++j) {
-        const double cj = cs_[j], sj = sn_[j];
-        const bool on = j <= sl;
-        const double m = on ? 1.0 : 0.0, mk = on ? (double)(j - start) : 0.0;
-        aC = fma(m, cj, aC);
-        aS = fma(m, sj, aS);
-        aJC = fma(mk, cj, aJC);
-        aJS = fma(mk, sj, aJS);
-      }
-      Sxv[b] = dt * aC;
-      Syv[b] = dt * aS;
-      // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
-      Sxw[b] = -vdt * dt * aJS;
-      Syw[b] = vdt * dt * aJC;
-#pragma unroll
-      for (int q = 0; q < b; ++q) {
-        Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
-        Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
-      }
-      const int cnt = min(max(sl + 1 - start, 0), end - start);
-      Sthw[b] = dt * (double)max(cnt, 0);
+    for (int q = 0; q < b; ++q) {
+      Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
+      Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
     }
+    const int cnt = min(max(sl + 1 - start, 0), end - start);
+    Sthw[b] = dt * (double)max(cnt, 0);
   }
 
   SMPC_STAMP(c, 4);
