@@ -342,6 +342,11 @@ int smpc_select_command_batch(smpc_handle* h, int32_t B, int32_t T, int32_t traj
  * 3 1/sqrt(a) | 4 a / b | 5 raw v_rcp_f64(a) | 6 raw v_rsq_f64(a). out1 may be NULL unless fn == 2. */
 int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1);
 
+/* Diagnostic: measured FP64 vector peak of the device in TFLOP/s (independent v_fma_f64 chains, `iters` x 64 fused
+ * multiply-adds per lane, 8 waves per SIMD, best of three launches) — the denominator of the FP64-VALU roofline
+ * bench.py reports. Returns < 0 on error. */
+double smpc_fp64_peak_probe(smpc_handle* h, int32_t iters);
+
 /* Timing of the most recent kernel launched by this handle, measured with HIP events on the handle's
  * stream. Returns milliseconds, <0 if unavailable. Synchronises the stream. */
 double smpc_last_kernel_ms(smpc_handle* h);

@@ -217,6 +217,7 @@ EXPORTED_SYMBOLS = [
     "smpc_trajectorize_path_batch",
     "smpc_select_command_batch",
     "smpc_math_probe",
+    "smpc_fp64_peak_probe",
     "smpc_stage_people_batch",
     "smpc_last_kernel_ms",
     "smpc_last_error",

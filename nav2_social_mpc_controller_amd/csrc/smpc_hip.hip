@@ -76,6 +76,24 @@ __global__ void smpc_math_probe_kernel(const ProbeParams) {
 }
 }  // namespace smpc
 
+namespace smpc {
+// FP64 vector peak probe (SURVEY §7 asks for the denominator of the FP64 roofline to be measured, not assumed):
+// eight independent v_fma_f64 chains per lane, nothing else in the loop.
+__global__ __launch_bounds__(256) void smpc_fp64_peak_kernel(double* out, int iters) {
+  double a0 = 1.0 + threadIdx.x * 1e-9, a1 = a0 + 1e-9, a2 = a0 + 2e-9, a3 = a0 + 3e-9;
+  double a4 = a0 + 4e-9, a5 = a0 + 5e-9, a6 = a0 + 6e-9, a7 = a0 + 7e-9;
+  const double m = 0.999999999, c = 1e-9;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a0 = fma(a0, m, c); a1 = fma(a1, m, c); a2 = fma(a2, m, c); a3 = fma(a3, m, c);
+      a4 = fma(a4, m, c); a5 = fma(a5, m, c); a6 = fma(a6, m, c); a7 = fma(a7, m, c);
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+}  // namespace smpc
+
 struct smpc_handle {
   smpc_params prm;
   int device;
@@ -757,6 +775,28 @@ int smpc_stage_people_batch(smpc_handle* h, const smpc_scene_batch* sb, double* 
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   return SMPC_OK;
+}
+
+double smpc_fp64_peak_probe(smpc_handle* h, int32_t iters) {
+  if (!h || iters < 1) { set_error("bad arguments to smpc_fp64_peak_probe"); return -1.0; }
+  if (hipSetDevice(h->device) != hipSuccess) return -1.0;
+  const int blocks = h->num_cu * 8, threads = 256;   // 8 waves per SIMD
+  double* out = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&out), (size_t)blocks * threads * sizeof(double)) != hipSuccess) return -1.0;
+  double best = -1.0;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(h->ev0, h->stream);
+    hipLaunchKernelGGL(smpc::smpc_fp64_peak_kernel, dim3(blocks), dim3(threads), 0, h->stream, out, iters);
+    (void)hipEventRecord(h->ev1, h->stream);
+    if (hipEventSynchronize(h->ev1) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess || ms <= 0.f) break;
+    const double flop = 2.0 * 64.0 * (double)iters * (double)blocks * (double)threads;
+    const double tf = flop / (ms * 1e-3) / 1e12;
+    if (tf > best) best = tf;
+  }
+  (void)hipFree(out);
+  return best;
 }
 
 int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1) {

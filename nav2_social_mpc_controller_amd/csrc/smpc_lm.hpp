@@ -227,7 +227,10 @@ template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1
   if (fb == 0.0) return b;
   if (!((fa < 0.0) != (fb < 0.0)) || !(fa == fa) || !(fb == fb)) return __builtin_nan("");
   const bool neg_lo = fa < 0.0;
-  double xl = a, xh = b, x = 0.5 * (a + b);
+  // start from the secant point of the bracket (inside it, since the signs differ); Newton from there, bisection
+  // whenever a step leaves the shrinking bracket
+  double xl = a, xh = b, x = a - fa * (b - a) * fast_rcp(fb - fa);
+  if (!(x > a && x < b)) x = 0.5 * (a + b);
   for (int it = 0; it < 80; ++it) {
     double fx, dfx;
     horner_d<D>(p, x, fx, dfx);
@@ -265,6 +268,21 @@ __device__ inline void quartic_roots_in_range_lanes(const double (&q)[5], double
     e1 = fmin(fmax(fmax(x1, x2), lo), hi);
   }
   const double d1[4] = {4.0 * q[0], 3.0 * q[1], 2.0 * q[2], q[3]};
+  {
+    // The common shape of a line-search interpolant: q' (the cubic d1) keeps one sign on [lo, hi] — its extrema over the
+    // interval are at the ends and at the roots e0, e1 of q'' — so q is monotone there and has at most one root: one
+    // bracketed iteration, the same in every lane, instead of the two lane-parallel isolation stages below.
+    double va, vb, vc, vd, t;
+    horner_d<3>(d1, lo, va, t); horner_d<3>(d1, hi, vb, t); horner_d<3>(d1, e0, vc, t); horner_d<3>(d1, e1, vd, t);
+    const double mn = fmin(fmin(va, vb), fmin(vc, vd)), mx = fmax(fmax(va, vb), fmax(vc, vd));
+    const bool one_sign = (mn > 0.0) || (mx < 0.0);
+    if (one_sign) {  // decided per slot (the value is the same in all its lanes): a result never depends on the wave's other scene
+      const double root = bracketed_root<4>(q, lo, hi);
+      roots[0] = root;
+      roots[1] = roots[2] = roots[3] = __builtin_nan("");
+      return;
+    }
+  }
   const double pa = (r == 0) ? lo : (r == 1) ? e0 : e1;
   const double pb = (r == 0) ? e0 : (r == 1) ? e1 : hi;
   const double s = bracketed_root<3>(d1, pa, pb);

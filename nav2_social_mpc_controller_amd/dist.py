@@ -1,7 +1,8 @@
 """Batch split over the GPUs of one node: every scene is an independent NLLS problem
 (reference src/optimizer.cpp:241-381 builds one ceres::Problem per call), so the path shards with NO data-path
 collective. One process per GPU; scenes are regenerated per rank from (seed, scene_id). torch.distributed
-(RCCL on GPUs, gloo in CPU tests) is used only for the bench's barrier / max-time / a few summary scalars."""
+(RCCL on GPUs, gloo in CPU tests) is used only for the bench's barrier / max-time / a few summary scalars and the
+all_gather of the optimised parameters for the result check on rank 0."""
 import os
 from typing import Tuple
 
@@ -36,3 +37,17 @@ def reduce_summary(local: dict, device=None) -> dict:
         dist.all_reduce(t, op=dist.ReduceOp.MAX if k.startswith("max_") else dist.ReduceOp.SUM)
         out[k] = float(t.item())
     return out
+
+
+def gather_params(params):
+    """the optimised parameter blocks of every rank on every rank, [world][B][P] (all_gather over RCCL /
+    gloo; 8 x 8192 x 6 doubles = 3.1 MB at BASELINE configs[3]). World size 1: the tensor itself with a leading axis."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return params.unsqueeze(0)
+    world = dist.get_world_size()
+    out = [torch.empty_like(params) for _ in range(world)]
+    dist.all_gather(out, params.contiguous())
+    return torch.stack(out, dim=0)

@@ -73,6 +73,8 @@ def load_library():
     lib.smpc_select_command_batch.restype = C.c_int
     lib.smpc_stage_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.c_void_p]
     lib.smpc_stage_people_batch.restype = C.c_int
+    lib.smpc_fp64_peak_probe.argtypes = [C.c_void_p, C.c_int32]
+    lib.smpc_fp64_peak_probe.restype = C.c_double
     lib.smpc_math_probe.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 4
     lib.smpc_math_probe.restype = C.c_int
     lib.smpc_last_kernel_ms.argtypes = [C.c_void_p]
@@ -124,6 +126,10 @@ class BatchSolver:
         _check(self.lib, self.lib.smpc_math_probe(self._h, int(fn), n, a.ctypes.data, None if bb is None else bb.ctypes.data,
                                                   o0.ctypes.data, o1.ctypes.data), "smpc_math_probe")
         return o0, o1
+
+    def fp64_peak_tflops(self, iters: int = 20000) -> float:
+        """Measured FP64 vector peak of this device (smpc_fp64_peak_probe)."""
+        return float(self.lib.smpc_fp64_peak_probe(self._h, int(iters)))
 
     def last_kernel_ms(self) -> float:
         return float(self.lib.smpc_last_kernel_ms(self._h))

@@ -18,7 +18,7 @@ HEADER = os.path.join(ROOT, "include", "smpc.h")
 def _declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(smpc_[a-z_]+)\s*\(", src)
+    names = re.findall(r"\b(smpc_[a-z0-9_]+)\s*\(", src)
     return sorted(set(names))
 
 

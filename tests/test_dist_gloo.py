@@ -35,8 +35,11 @@ def _worker(rank, world, port, total, q):
     res = O.solve(p, sc)
     dist.barrier()
     summ = D.reduce_summary({"scenes": hi - lo, "iterations": int(res["iterations"].sum()),
-                             "max_seconds": 0.5 + rank, "cmd_sum": float(res["cmds"].sum())})
-    q.put((rank, lo, hi, summ, res["cmds"]))
+                             "max_seconds": 0.5 + rank, "cmd_sum": float(res["cmds"].sum()),
+                             # the bench's per-rank parity record: MAX over ranks of max |dcmd|, SUM of the counts
+                             "max_abs_dcmd": 1e-9 * (rank + 1), "scenes_over_1e-5": rank})
+    gathered = D.gather_params(torch.from_numpy(res["params"]))      # [world][B/world][P] on every rank
+    q.put((rank, lo, hi, summ, res["cmds"], gathered.numpy()))
     dist.destroy_process_group()
 
 
@@ -60,7 +63,10 @@ def test_two_rank_weak_sharding_matches_single_process():
     whole = O.solve(prm, make_scenes(prm, total, 3, map_cells=40, seed=5))
     cmds = np.concatenate([g[4] for g in got], axis=0)
     assert np.array_equal(cmds, whole["cmds"])                      # shards == the unsharded batch, bit for bit
-    for _, lo, hi, summ, _ in got:
+    for _, lo, hi, summ, _, gathered in got:
+        assert gathered.shape == (world, total // world, whole["params"].shape[1])
+        assert np.array_equal(gathered.reshape(total, -1), whole["params"])   # all_gather: every rank holds every shard
+        assert summ["max_abs_dcmd"] == 2e-9 and summ["scenes_over_1e-5"] == 1   # MAX / SUM of the parity record
         assert summ["scenes"] == total                              # SUM
         assert summ["iterations"] == int(whole["iterations"].sum())
         assert summ["max_seconds"] == 1.5                           # MAX over ranks
