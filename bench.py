@@ -197,6 +197,12 @@ def main():
                     help="consecutive steps are issued round-robin on this many HIP streams (one solver handle each)")
     args = ap.parse_args()
 
+    # Only the JSON line may reach stdout: libraries underneath (RCCL prints a version banner at communicator creation)
+    # write to file descriptor 1 too. Keep the real stdout aside and point fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -436,7 +442,8 @@ def main():
             line["config"]["cfg5"] = shape_record(cfg5, 8192, 16, device, local_rank)
             line["config"]["params_yaml_n3"] = shape_record(OptimizerParams.params_yaml(), 8192, 3, device, local_rank)
             line["config"]["closed_loop"] = closed_loop_extras(prm, scenes, local_rank)
-        print(json.dumps(line))
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
