@@ -97,7 +97,7 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
   L.inc = o; o += 4 * (T + 1);
   L.cst = o; o += 8;
   L.lanec = o; o += 3 * T;
-  L.lm = o; if (with_lm) o += P * P + 6 * P + 24;
+  L.lm = o; if (with_lm) o += 2 * P * P + 6 * P + 4 * P + 18 * P + 24;  // Hs, Lw, six vectors, hand-over, reductions, scalars
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
   L.scratch = o; if (with_lm) o += 96;  // generic line-search interpolation fallback
   L.total = (o + 3) & ~3;  // 32-byte multiple: records are moved as 4-double vectors
@@ -958,7 +958,6 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       fr[P] = wf * lin * lin + wf * ang * ang;
     }
     double* red = c.wave_lds + c.slot * gram_red_doubles(W) + sl * (kGramChunk + 1);
-    const double* red_col = c.wave_lds + c.slot * gram_red_doubles(W) + sl;
     double hv[kGramChunk];
     int cnt = 0, chunk_base = 0;  // compile-time after unrolling
     auto flush = [&](int n, int base, int col_lo, int col_hi) {
@@ -966,10 +965,18 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
       for (int i = 0; i < kGramChunk; ++i) if (i < n) red[i] = hv[i];
       wave_lds_fence();
+      // two levels: lane (part, v) = (sl / 16, sl % 16) adds up value v of the 16 lanes of its part, then the W / 16
+      // parts are combined by butterfly shuffles — W / 16 times fewer additions per lane than one lane per value
+      const int vsel = sl & (kGramChunk - 1), part = sl / kGramChunk;
+      double tot = 0.0;
+      {
+        const double* col = c.wave_lds + c.slot * gram_red_doubles(W) + (part * kGramChunk) * (kGramChunk + 1) + vsel;
+#pragma unroll
+        for (int l = 0; l < kGramChunk; ++l) tot += col[l * (kGramChunk + 1)];
+      }
+#pragma unroll
+      for (int off = kGramChunk; off < W; off <<= 1) tot += __shfl_xor(tot, off, W);
       if (sl < n) {
-        double tot = 0.0;
-#pragma unroll 8
-        for (int l = 0; l < W; ++l) tot += red_col[l * (kGramChunk + 1)];
         // packed (column-major upper triangle) index -> (a, b)
         const int pidx = base + sl;
         int bcol = col_lo;

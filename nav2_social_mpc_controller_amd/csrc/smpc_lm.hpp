@@ -388,47 +388,6 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
   return true;
 }
 
-// In-register Cholesky solve of (H + diag(D2)) y = g for P <= 20 (fully unrolled); H is the packed lower triangle
-// Hl[tri(i, j)], j <= i.
-__host__ __device__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-template <int P>
-__device__ inline bool cholesky_solve(const double (&Hl)[P * (P + 1) / 2], const double (&D2)[P], const double (&g)[P],
-                                      double (&y)[P]) {
-  double Lm[P * (P + 1) / 2], invd[P];
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < P; ++j) {
-    double d = Hl[tri(j, j)] + D2[j];
-#pragma unroll
-    for (int kk = 0; kk < j; ++kk) d -= Lm[tri(j, kk)] * Lm[tri(j, kk)];
-    if (!(d > 0.0) || !isfinite(d)) ok = false;
-    const double inv = rsqrt(d);  // 1 / l_jj; l_jj itself is never needed
-    invd[j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < P; ++i) {
-      double v = Hl[tri(i, j)];
-#pragma unroll
-      for (int kk = 0; kk < j; ++kk) v -= Lm[tri(i, kk)] * Lm[tri(j, kk)];
-      Lm[tri(i, j)] = v * inv;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < P; ++i) {
-    double v = g[i];
-#pragma unroll
-    for (int kk = 0; kk < i; ++kk) v -= Lm[tri(i, kk)] * y[kk];
-    y[i] = v * invd[i];
-  }
-#pragma unroll
-  for (int i = P - 1; i >= 0; --i) {
-    double v = y[i];
-#pragma unroll
-    for (int kk = i + 1; kk < P; ++kk) v -= Lm[tri(kk, i)] * y[kk];
-    y[i] = v * invd[i];
-  }
-  return ok;
-}
-
 // std::min(std::max(v, lo), hi) of parameter_block.h Plus(): a NaN stays a NaN (fmin / fmax alone would drop it and a
 // NaN warm start would be solved from the lower bound instead of failing its initial evaluation like Ceres)
 __device__ inline double clampd(double v, double lo, double hi) { return (v != v) ? v : fmin(fmax(v, lo), hi); }
@@ -455,6 +414,10 @@ struct LmRegs {  // slot-uniform integers / flags kept in registers
 #ifndef SMPC_SOLVE_MIN_WAVES
 #define SMPC_SOLVE_MIN_WAVES 2   // waves per SIMD the solve kernel's register allocation must allow
 #endif
+// The LM vectors and matrices of a slot are spread over its lanes: lane q < P owns parameter q (its entry of x, of the
+// trial point, of the step, row q of the scaled Gram and of its Cholesky factor). One instruction then updates all P
+// entries; sums over the parameters go through a few LDS words in index order (the same order a serial loop would
+// add them in). Nothing P x P lives in registers, so the P = 8..12 instantiations do not spill.
 template <int NB, int W>
 __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(const KParams) {
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
@@ -473,18 +436,38 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   c.ag = k.people_rec;
   const auto& prm = k.prm;
   const int T = k.T;
-  double* Hs = c.lds + c.L.lm;   // [P*P reserved] scaled J^T J at the current point, packed lower triangle tri(i, j)
-  double* gs = Hs + P * P;       // [P] scaled gradient
+  double* Hs = c.lds + c.L.lm;   // [P][P] scaled J^T J at the current point, dense
+  double* Lw = Hs + P * P;       // [P][P] rows of the Cholesky factor of the damped system
+  double* gs = Lw + P * P;       // [P] scaled gradient
   double* gu = gs + P;           // [P] unscaled gradient
   double* xc = gu + P;           // [P] current point
   double* xt = xc + P;           // [P] trial point (input of the sweep)
   double* dl = xt + P;           // [P] delta (unscaled step of this iteration)
   double* sc = dl + P;           // [P] Jacobi scaling
-  double* sv = sc + P;           // scalars [24]
+  double* bc = sc + P;           // [4][P] hand-over words: pivots, forward / backward solutions, scaled step
+  double* rs = bc + 4 * P;       // [6][3][P] reduction words, one block per call site
+  double* sv = rs + 18 * P;      // scalars [24]
   double* scratch = c.lds + c.L.scratch;
   const int blast = (k.CH - 1) / k.bl;
-  auto lo = [&](int q) -> double { return (q / 2 < k.nbounded) ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308; };
-  auto hi = [&](int q) -> double { return (q / 2 < k.nbounded) ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308; };
+  const int q = c.sl;            // the parameter this lane owns in the LM algebra
+  const bool act = q < P;
+  const int qc = act ? q : 0;    // in-range index for lanes that only tag along
+  // bounds of parameter q (src/optimizer.cpp:373-379: blocks 0..CH/bl-1 are bounded)
+  const bool bounded = act && (q >> 1) < k.nbounded;
+  const double lo_q = bounded ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
+  const double hi_q = bounded ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
+  const unsigned long long slot_bits = (W == 64) ? ~0ull : (0xffffffffull << (32 * slot));
+  auto slot_any = [&](bool pred) -> bool { return (__ballot(pred) & slot_bits) != 0ull; };
+  // sums / maximum over the parameters: every active lane leaves its terms in the site's words, then every lane adds
+  // them up in index order
+  auto reduce3 = [&](int site, double a, double b, double m, double& sa, double& sb, double& sm) {
+    double* w3 = rs + site * 3 * P;
+    if (act) { w3[q] = a; w3[P + q] = b; w3[2 * P + q] = m; }
+    wave_lds_fence();
+    sa = 0.0; sb = 0.0; sm = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) { sa += w3[i]; sb += w3[P + i]; sm = fmax(sm, w3[2 * P + i]); }
+  };
 
   LmRegs R;
   R.phase = PH_FETCH;
@@ -508,13 +491,13 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
       if (scene < k.B) {
         load_scene<W>(c, scene);
         ever_loaded = true;
-        const double* xin = k.init_params + (size_t)scene * P;
-        double xn = 0.0;
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-          const double v = clampd(xin[q] + 0.0, lo(q), hi(q));  // Plus(x, 0): project the start point (A.4)
-          xc[q] = v; xt[q] = v; xn += v * v;
+        double v = 0.0;
+        if (act) {
+          v = clampd(k.init_params[(size_t)scene * P + q] + 0.0, lo_q, hi_q);  // Plus(x, 0): project the start point (A.4)
+          xc[q] = v; xt[q] = v;
         }
+        double xn, u0, u1;
+        reduce3(0, v * v, 0.0, 0.0, xn, u0, u1);
         sv[S_XNORM] = sqrt(xn);
         R.phase = PH_INIT;
         R.iter = 0; R.evals = 0; R.num_invalid = 0;
@@ -524,8 +507,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         if (!ever_loaded) {  // keep the sweep's memory accesses in bounds for a slot that never got a scene
           load_scene<W>(c, 0);
           ever_loaded = true;
-#pragma unroll
-          for (int q = 0; q < P; ++q) xt[q] = 0.0;
+          if (act) xt[q] = 0.0;
         }
         R.phase = PH_IDLE;
       }
@@ -535,37 +517,37 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
     const GramView GH = sweep<NB, W, false>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
-    const bool finite = gram_finite<P>(GH);
+    // usable iff every residual and Jacobian entry was finite: a non-finite one makes its diagonal Gram entry non-finite
+    const bool finite = !slot_any(c.sl <= P && !isfinite(GH.base[min(c.sl, P) * GH.ld + min(c.sl, P)]));
     const double val = 0.5 * GH(P, P);
     bool new_iteration = false;
 
     // ---------------------------------------------------------------- advance the slot's state machine
-    auto adopt_trial_point = [&]() {  // x <- xt, Hs/gs/gu/gmax from G (scaled by the fixed Jacobi scaling)
-      double xn = 0.0, gmax = 0.0;
-      double scr[P];
+    auto adopt_trial_point = [&]() {  // x <- xt, Hs / gs / gu / gmax from G (scaled by the fixed Jacobi scaling)
+      double xa = 0.0, gm = 0.0;
+      if (act) {
+        xa = xt[q];
+        xc[q] = xa;
+        const double scq = sc[q];
+        const double* grow = GH.base + q * GH.ld;
 #pragma unroll
-      for (int a = 0; a < P; ++a) scr[a] = sc[a];
-#pragma unroll
-      for (int a = 0; a < P; ++a) {
-        const double xa = xt[a];
-        xc[a] = xa;
-        xn += xa * xa;
-#pragma unroll
-        for (int b = 0; b <= a; ++b) Hs[tri(a, b)] = GH(a, b) * scr[a] * scr[b];  // the Gram is bitwise symmetric
-        const double g = GH(a, P);
-        gu[a] = g; gs[a] = g * scr[a];
-        gmax = fmax(gmax, fabs(xa - clampd(xa - g, lo(a), hi(a))));
+        for (int b = 0; b < P; ++b) Hs[q * P + b] = grow[b] * scq * sc[b];  // the Gram is bitwise symmetric
+        const double g = grow[P];
+        gu[q] = g; gs[q] = g * scq;
+        gm = fabs(xa - clampd(xa - g, lo_q, hi_q));
       }
+      double xn, u0, gmax;
+      reduce3(1, xa * xa, 0.0, gm, xn, u0, gmax);
       sv[S_XNORM] = sqrt(xn);
       sv[S_GMAX] = gmax;
     };
     auto candidate = [&]() {  // A.9 tests on the candidate = current trial point; A.10 strategy update
       const double cost = sv[S_COST];
       const double cand_cost = R.cur_vv ? sv[S_CUR_V] : 1.7976931348623157e308;
-      double step_norm = 0.0;
-#pragma unroll
-      for (int q = 0; q < P; ++q) { const double d = xc[q] - xt[q]; step_norm += d * d; }
-      step_norm = sqrt(step_norm);
+      const double d = act ? xc[q] - xt[q] : 0.0;
+      double sn2, u0, u1;
+      reduce3(2, d * d, 0.0, 0.0, sn2, u0, u1);
+      const double step_norm = sqrt(sn2);
       const bool tol_allowed = !prm.fixed_iterations && (!prm.tol_needs_successful_step || R.at_least_one);
       if (tol_allowed && step_norm <= prm.param_tol * (sv[S_XNORM] + prm.param_tol)) {
         R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_PARAMETER_TOL; R.phase = PH_DONE; return;
@@ -596,8 +578,8 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
       if (!finite) {
         R.status = SMPC_FAILURE; R.reason = SMPC_REASON_EVAL_FAILED; R.phase = PH_DONE;
       } else {
-#pragma unroll
-        for (int q = 0; q < P; ++q) sc[q] = 1.0 / (1.0 + sqrt(GH(q, q)));  // Jacobi scaling (A.5)
+        if (act) sc[q] = 1.0 / (1.0 + sqrt(GH.base[q * GH.ld + q]));  // Jacobi scaling (A.5)
+        wave_lds_fence();
         adopt_trial_point();
         sv[S_RADIUS] = 1e4; sv[S_DECF] = 2.0;
         new_iteration = true;
@@ -605,9 +587,9 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     } else if (R.phase == PH_LS) {
       ++R.evals;
       // record the sample just evaluated (LineSearchFunction::Evaluate, A.8)
-      double gd = 0.0;
-#pragma unroll
-      for (int q = 0; q < P; ++q) gd += dl[q] * GH(q, P);
+      const double dq = act ? dl[q] : 0.0;
+      double gd, u0, u1;
+      reduce3(3, act ? dq * GH.base[q * GH.ld + P] : 0.0, 0.0, 0.0, gd, u0, u1);
       R.cur_vv = finite && isfinite(val);
       R.cur_gv = R.cur_vv && isfinite(gd);
       sv[S_CUR_V] = val; sv[S_CUR_G] = gd;
@@ -615,8 +597,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
       if (R.n_samples == 1) { sv[S_FIRST_V] = val; R.first_vv = R.cur_vv; }  // the full step: candidate if the search fails
       if (R.cur_vv && !(val > sv[S_COST] + 1e-4 * sv[S_GD0] * alpha)) {
         // Armijo satisfied: delta *= alpha; the candidate is this very point
-#pragma unroll
-        for (int q = 0; q < P; ++q) dl[q] *= alpha;
+        if (act) dl[q] = dq * alpha;
         candidate();
       } else {
         ++R.ls_iters;
@@ -635,16 +616,14 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         if (!failed) {
           sv[S_PREV_X] = alpha; sv[S_PREV_V] = val; sv[S_PREV_G] = gd; R.prev_vv = R.cur_vv; R.prev_gv = R.cur_gv;
           sv[S_CUR_X] = step_size;
-#pragma unroll
-          for (int q = 0; q < P; ++q) xt[q] = clampd(xc[q] + step_size * dl[q], lo(q), hi(q));
+          if (act) xt[q] = clampd(xc[q] + step_size * dq, lo_q, hi_q);
           ++R.n_samples;
         } else if (R.n_samples > 1) {
           // Line search failed: delta unchanged, the candidate is the full step again (the first sample). Its cost is
           // known; its Gram is only needed if the step were accepted, which a step that failed the Armijo test at
           // alpha = 1 cannot be (cost - value_1 < -1e-4 g.delta < 1e-3 model_cost_change). Only in that never-seen case
           // the point is swept again (PH_REEVAL) so that the accepted state is built from its own Gram.
-#pragma unroll
-          for (int q = 0; q < P; ++q) xt[q] = clampd(xc[q] + dl[q], lo(q), hi(q));
+          if (act) xt[q] = clampd(xc[q] + dq, lo_q, hi_q);
           const double v1 = R.first_vv ? sv[S_FIRST_V] : 1.7976931348623157e308;
           const bool would_accept = R.first_vv && ((sv[S_COST] - v1) / sv[S_MCC] > 1e-3);
           if (would_accept) {
@@ -652,6 +631,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
           } else {
             R.cur_vv = R.first_vv;
             sv[S_CUR_V] = v1;
+            wave_lds_fence();
             candidate();
           }
         } else {
@@ -673,50 +653,81 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         if (sv[S_RADIUS] <= 1e-32) { R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_MIN_RADIUS; R.phase = PH_DONE; break; }
         ++R.iter;
         R.step_successful = false;
-        double step[P], D2[P], Hl[P * (P + 1) / 2], gsr[P];
         const double radius = sv[S_RADIUS];
-#pragma unroll
-        for (int q = 0; q < P * (P + 1) / 2; ++q) Hl[q] = Hs[q];  // one batch of LDS reads for the whole iteration
-#pragma unroll
-        for (int q = 0; q < P; ++q) gsr[q] = gs[q];
         const double inv_radius = 1.0 / radius;
+        // row q of Hs + diag(D^2), D^2 = clamp(diag, 1e-6, 1e32) / radius: the LM strategy (A.6)
+        double arow[P], Lr[P], invd[P];
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-          D2[q] = clampd(Hl[tri(q, q)], 1e-6, 1e32) * inv_radius;  // (sqrt(diag / radius))^2 of the LM strategy (A.6)
+        for (int j = 0; j < P; ++j) arow[j] = Hs[qc * P + j];
+        const double gsq = act ? gs[q] : 0.0;
+        const double d2 = clampd(Hs[qc * P + qc], 1e-6, 1e32) * inv_radius;
+        // Cholesky, one row per lane, column by column: s = a_ij - sum_k<j L_ik L_jk; lane j's s is the pivot
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          double s_ = arow[j] + ((j == q) ? d2 : 0.0);
+#pragma unroll
+          for (int kk = 0; kk < j; ++kk) s_ = fma(-Lr[kk], Lw[j * P + kk], s_);
+          if (q == j) bc[j] = s_;
+          wave_lds_fence();
+          const double dpiv = bc[j];
+          ok = ok && (dpiv > 0.0) && isfinite(dpiv);
+          const double inv = rsqrt_pos(fmax(dpiv, 1e-300));  // 1 / l_jj (never used when the pivot is not positive)
+          invd[j] = inv;
+          Lr[j] = s_ * inv;
+          if (act && q > j) Lw[q * P + j] = Lr[j];
+          wave_lds_fence();
         }
-        bool valid = cholesky_solve<P>(Hl, D2, gsr, step);
+        // forward substitution L y = gs, backward L^T z = y; the step is -z
+        double accf = gsq, yq = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < P; ++kk) {
+          const double yk_own = accf * invd[kk];
+          if (q == kk) { bc[P + kk] = yk_own; yq = yk_own; }
+          wave_lds_fence();
+          const double yk = bc[P + kk];
+          accf = fma((q > kk) ? -Lr[kk] : 0.0, yk, accf);
+        }
+        double accb = yq, zq = 0.0;
+#pragma unroll
+        for (int kk = P - 1; kk >= 0; --kk) {
+          const double zk_own = accb * invd[kk];
+          if (q == kk) { bc[2 * P + kk] = zk_own; zq = zk_own; }
+          wave_lds_fence();
+          const double zk = bc[2 * P + kk];
+          accb = fma((act && q < kk) ? -Lw[kk * P + qc] : 0.0, zk, accb);
+        }
+        const double stepq = act ? -zq : 0.0;
+        bool valid = ok && !slot_any(act && !isfinite(stepq));
         double mcc = 0.0;
-#pragma unroll
-        for (int q = 0; q < P; ++q) { if (!isfinite(step[q])) valid = false; step[q] = -step[q]; }
         if (valid) {
-          double sg = 0.0, sHs = 0.0;
+          if (act) bc[3 * P + q] = stepq;
+          wave_lds_fence();
+          double rowv = 0.0;
 #pragma unroll
-          for (int a = 0; a < P; ++a) {
-            sg += step[a] * gsr[a];
-            double row = 0.0;
-#pragma unroll
-            for (int b = 0; b < P; ++b) row += Hl[a >= b ? tri(a, b) : tri(b, a)] * step[b];
-            sHs += step[a] * row;
-          }
+          for (int b = 0; b < P; ++b) rowv = fma(arow[b], bc[3 * P + b], rowv);
+          double sg, sHs, u1;
+          reduce3(4, stepq * gsq, act ? stepq * rowv : 0.0, 0.0, sg, sHs, u1);
           mcc = -sg - 0.5 * sHs;
           valid = mcc > 0.0;
         }
         if (!valid) {
           if (++R.num_invalid >= 5) { R.status = SMPC_FAILURE; R.reason = SMPC_REASON_INVALID_STEPS; R.phase = PH_DONE; break; }
           sv[S_RADIUS] = radius / sv[S_DECF]; sv[S_DECF] *= 2.0;
+          wave_lds_fence();
           continue;
         }
         R.num_invalid = 0;
         sv[S_MCC] = mcc;
-        double gd0 = 0.0, dirmax = 0.0;
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-          const double d = step[q] * sc[q];
-          dl[q] = d;
-          gd0 += gu[q] * d;
-          dirmax = fmax(dirmax, fabs(d));
-          xt[q] = clampd(xc[q] + 1.0 * d, lo(q), hi(q));
+        double dq = 0.0, gq = 0.0;
+        if (act) {
+          dq = stepq * sc[q];
+          dl[q] = dq;
+          gq = gu[q] * dq;
+          xt[q] = clampd(xc[q] + 1.0 * dq, lo_q, hi_q);
         }
+        double gd0, u0, dirmax;
+        reduce3(5, gq, 0.0, fabs(dq), gd0, u0, dirmax);
         sv[S_GD0] = gd0; sv[S_DIRMAX] = dirmax;
         sv[S_CUR_X] = 1.0;
         R.prev_vv = R.prev_gv = false;
@@ -728,6 +739,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 
     // ---------------------------------------------------------------- finished: outputs, a12 unpack
     if (R.phase == PH_DONE) {
+      wave_lds_fence();
       const size_t s = c.scene;
       if (c.sl == 0) {
         if (k.o_status) k.o_status[s] = R.status;
