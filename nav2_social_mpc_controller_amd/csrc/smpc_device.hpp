@@ -335,6 +335,47 @@ __device__ inline void cubic_hermite(double p0, double p1, double p2, double p3,
   df = c + x * (2.0 * b + 3.0 * a * x);
 }
 
+// The same interpolation split in two, so that the sweep can request the 4 x 4 patch as soon as the pose is known and
+// consume it after the agent loop (the 16 dependent byte loads were 6 % of a lone solve launch): the patch is fetched
+// as four unaligned dwords, one per row, starting at column clamp(col - 1, 0, size_x - 4); the byte of clamped column
+// cc is then byte (cc - start) of its row's dword — also at the edges, where several taps share a cell.
+struct CostPatch {
+  uint32_t row[4];   // bytes start .. start + 3 of the four clamped rows
+  int sh[4];         // bit offset of tap j inside a row dword
+  double tr, tc;     // fractional parts r - floor(r), c - floor(c)
+};
+
+__device__ inline void bicubic_fetch(const uint8_t* __restrict__ map, int size_x, int size_y, double r, double c, CostPatch& p) {
+  const double fr = floor(r), fc = floor(c);
+  const double frc = fmin(fmax(fr, -4.0), (double)size_y + 4.0), fcc = fmin(fmax(fc, -4.0), (double)size_x + 4.0);
+  const int row = (int)frc, col = (int)fcc;
+  const int start = min(max(col - 1, 0), size_x - 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p.sh[j] = 8 * (min(max(col - 1 + j, 0), size_x - 1) - start);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = min(max(row - 1 + i, 0), size_y - 1);
+    uint32_t v;
+    __builtin_memcpy(&v, map + (size_t)rr * size_x + start, 4);  // unaligned dword
+    p.row[i] = v;
+  }
+  p.tr = r - fr; p.tc = c - fc;
+}
+
+__device__ inline void bicubic_eval(const CostPatch& p, double& f, double& dfdr, double& dfdc) {
+  double fv[4], dv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = (double)((p.row[i] >> p.sh[j]) & 0xffu);
+    cubic_hermite(t[0], t[1], t[2], t[3], p.tc, fv[i], dv[i]);
+  }
+  double unused;
+  cubic_hermite(fv[0], fv[1], fv[2], fv[3], p.tr, f, dfdr);
+  cubic_hermite(dv[0], dv[1], dv[2], dv[3], p.tr, dfdc, unused);
+}
+
 __device__ inline void bicubic(const uint8_t* __restrict__ map, int size_x, int size_y, double r, double c,
                                double& f, double& dfdr, double& dfdc) {
   const double fr = floor(r), fc = floor(c);
@@ -597,6 +638,11 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   }
   const int t1 = min(sl + 1, T);
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
+  // a5 obstacle: the costmap patch under the front point is requested now and used after the agent loop
+  const bool wide_map = k.size_x >= 4;
+  const double ob_ic = (X + 0.25 * c1 - cst[4]) / k.resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) / k.resolution;
+  CostPatch patch;
+  if (wide_map) bicubic_fetch(c.map, k.size_x, k.size_y, ob_ir, ob_ic, patch);
 
   SMPC_STAMP(c, 2);
   // ---- a3 social work + a4 proxemics: walk the agents of step sl
@@ -697,30 +743,35 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   }
 
   SMPC_STAMP(c, 3);
-  // ---- sensitivities S of pose_{sl+1} (after the agent loop: keeps them out of its register budget), from the scans
+  // ---- sensitivities S of pose_{sl+1}, from the scans. K1 needs them for every row it forms, so right after the agent
+  // loop; the solve kernel only for the final M^T A M, so after the critics (they stay out of the critics' register
+  // budget, as the critics' sums stay out of theirs).
   double Sxv[NB], Syv[NB], Sxw[NB], Syw[NB], Sthw[NB];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int start = b * bl;
-    const int end = (b == NB - 1) ? T : (b + 1) * bl;
-    const int idx = (b < myb) ? end - 1 : tl;
-    const double m = (b <= myb) ? 1.0 : 0.0;
-    const double aC = m * scan_[idx], aS = m * scan_[(T + 1) + idx];
-    const double aJC = m * scan_[2 * (T + 1) + idx], aJS = m * scan_[3 * (T + 1) + idx];  // sums of (j - start) cos / sin
-    const double vdt = xp[2 * b] * dt;
-    Sxv[b] = dt * aC;
-    Syv[b] = dt * aS;
-    // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
-    Sxw[b] = -vdt * dt * aJS;
-    Syw[b] = vdt * dt * aJC;
-#pragma unroll
-    for (int q = 0; q < b; ++q) {
-      Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
-      Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
+  auto compute_sensitivities = [&]() {
+  #pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int start = b * bl;
+      const int end = (b == NB - 1) ? T : (b + 1) * bl;
+      const int idx = (b < myb) ? end - 1 : tl;
+      const double m = (b <= myb) ? 1.0 : 0.0;
+      const double aC = m * scan_[idx], aS = m * scan_[(T + 1) + idx];
+      const double aJC = m * scan_[2 * (T + 1) + idx], aJS = m * scan_[3 * (T + 1) + idx];  // sums of (j - start) cos / sin
+      const double vdt = xp[2 * b] * dt;
+      Sxv[b] = dt * aC;
+      Syv[b] = dt * aS;
+      // d theta_j / d w_b = dt (j - start) inside block b; = dt * bl for every later step
+      Sxw[b] = -vdt * dt * aJS;
+      Syw[b] = vdt * dt * aJC;
+  #pragma unroll
+      for (int q = 0; q < b; ++q) {
+        Sxw[q] = fma(-vdt * dt * (double)bl, aS, Sxw[q]);
+        Syw[q] = fma(vdt * dt * (double)bl, aC, Syw[q]);
+      }
+      const int cnt = min(max(sl + 1 - start, 0), end - start);
+      Sthw[b] = dt * (double)max(cnt, 0);
     }
-    const int cnt = min(max(sl + 1 - start, 0), end - start);
-    Sthw[b] = dt * (double)max(cnt, 0);
-  }
+  };
+  if (kRows) compute_sensitivities();
 
   SMPC_STAMP(c, 4);
   // ---- per-step critics: residual r and its state-space gradient (gx, gy, gth; gv = direct derivative with respect
@@ -883,11 +934,10 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   SMPC_STAMP2(c, 1);  // velocity, goal, 2 x distance
   // a5 obstacle
   {
-    const double fxp = X + 0.25 * c1, fyp = Y + 0.25 * s1;
     const double inv_res = 1.0 / k.resolution;
-    const double ic = (fxp - cst[4]) / k.resolution, ir = (fyp - cst[5]) / k.resolution;
     double f, dfdr, dfdc;
-    bicubic(c.map, k.size_x, k.size_y, ir, ic, f, dfdr, dfdc);
+    if (wide_map) bicubic_eval(patch, f, dfdr, dfdc);
+    else bicubic(c.map, k.size_x, k.size_y, ob_ir, ob_ic, f, dfdr, dfdc);  // maps narrower than one patch: byte by byte
     const double r = w.obstacle_w * f;
     const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
     const double gth = w.obstacle_w * (dfdc * (-0.25 * s1) + dfdr * (0.25 * c1)) * inv_res;
@@ -939,6 +989,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       gt[P * Q + a] = v;
     }
   } else {
+    compute_sensitivities();
     // ---- the lane's share of the Gram: H = M^T A M, g = M^T b, cc; summed over the slot's lanes through LDS.
     if (!lane_live) {  // lanes beyond the horizon carry nothing (their A may hold anything, NaN included)
       Axx = Axy = Axt = Axv = Ayy = Ayt = Ayv = Att = Atv = Avv = 0.0;

@@ -425,39 +425,49 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   constexpr int S = kWave / W;
   extern __shared__ __attribute__((aligned(32))) double lds_all[];
   const int lane = threadIdx.x & 63;
-  const int slot = lane / W;
   Ctx c;
   c.kp = &k;
-  c.sl = lane - slot * W;
   c.L = make_layout(k.T, k.N, P, kLayoutSolve);
-  c.lds = lds_all + (size_t)slot * c.L.total;
-  c.wave_lds = lds_all + (size_t)S * c.L.total;
-  c.slot = slot;
   c.ag = k.people_rec;
   const auto& prm = k.prm;
   const int T = k.T;
-  double* Hs = c.lds + c.L.lm;   // [P][P] scaled J^T J at the current point, dense
-  double* Lw = Hs + P * P;       // [P][P] rows of the Cholesky factor of the damped system
-  double* gs = Lw + P * P;       // [P] scaled gradient
-  double* gu = gs + P;           // [P] unscaled gradient
-  double* xc = gu + P;           // [P] current point
-  double* xt = xc + P;           // [P] trial point (input of the sweep)
-  double* dl = xt + P;           // [P] delta (unscaled step of this iteration)
-  double* sc = dl + P;           // [P] Jacobi scaling
-  double* bc = sc + P;           // [4][P] hand-over words: pivots, forward / backward solutions, scaled step
-  double* rs = bc + 4 * P;       // [6][3][P] reduction words, one block per call site
-  double* sv = rs + 18 * P;      // scalars [24]
-  double* scratch = c.lds + c.L.scratch;
   const int blast = (k.CH - 1) / k.bl;
-  const int q = c.sl;            // the parameter this lane owns in the LM algebra
-  const bool act = q < P;
-  const int qc = act ? q : 0;    // in-range index for lanes that only tag along
-  // bounds of parameter q (src/optimizer.cpp:373-379: blocks 0..CH/bl-1 are bounded)
-  const bool bounded = act && (q >> 1) < k.nbounded;
-  const double lo_q = bounded ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
-  const double hi_q = bounded ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
-  const unsigned long long slot_bits = (W == 64) ? ~0ull : (0xffffffffull << (32 * slot));
-  auto slot_any = [&](bool pred) -> bool { return (__ballot(pred) & slot_bits) != 0ull; };
+  // Everything below is derived from the lane index. It is re-derived at the top of every trip and again behind the
+  // sweep from a copy of the lane index the compiler cannot see through (an empty asm): otherwise these ~20 addresses
+  // and flags are computed once in the prologue, stay live through the whole kernel — the sweep runs at the VGPR limit —
+  // and come back as scratch reloads inside the loop.
+  int slot, q, qc;
+  bool act;
+  double *Hs, *Lw, *gs, *gu, *xc, *xt, *dl, *sc, *bc, *rs, *sv, *scratch;
+  int32_t* rw;
+  auto bind = [&](int lane_t) {
+    slot = lane_t / W;
+    c.sl = lane_t - slot * W;
+    c.slot = slot;
+    c.lds = lds_all + (size_t)slot * c.L.total;
+    c.wave_lds = lds_all + (size_t)S * c.L.total;
+    Hs = c.lds + c.L.lm;   // [P][P] scaled J^T J at the current point, dense
+    Lw = Hs + P * P;       // [P][P] rows of the Cholesky factor of the damped system
+    gs = Lw + P * P;       // [P] scaled gradient
+    gu = gs + P;           // [P] unscaled gradient
+    xc = gu + P;           // [P] current point
+    xt = xc + P;           // [P] trial point (input of the sweep)
+    dl = xt + P;           // [P] delta (unscaled step of this iteration)
+    sc = dl + P;           // [P] Jacobi scaling
+    bc = sc + P;           // [4][P] hand-over words: pivots, forward / backward solutions, scaled step
+    rs = bc + 4 * P;       // [6][3][P] reduction words, one block per call site
+    sv = rs + 18 * P;      // scalars [24]
+    rw = reinterpret_cast<int32_t*>(sv + S_COUNT);  // the state machine's integers, parked across the sweep
+    scratch = c.lds + c.L.scratch;
+    q = c.sl;              // the parameter this lane owns in the LM algebra
+    act = q < P;
+    qc = act ? q : 0;      // in-range index for lanes that only tag along
+  };
+  bind(lane);
+  auto slot_any = [&](bool pred) -> bool {
+    const unsigned long long slot_bits = (W == 64) ? ~0ull : (0xffffffffull << (32 * slot));
+    return (__ballot(pred) & slot_bits) != 0ull;
+  };
   // sums / maximum over the parameters: every active lane leaves its terms in the site's words, then every lane adds
   // them up in index order
   auto reduce3 = [&](int site, double a, double b, double m, double& sa, double& sb, double& sm) {
@@ -469,11 +479,27 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     for (int i = 0; i < P; ++i) { sa += w3[i]; sb += w3[P + i]; sm = fmax(sm, w3[2 * P + i]); }
   };
 
+  // The state machine's integers and flags live in LDS across the sweep (behind the scalars of sv[]): only the phase
+  // stays in a register there. The sweep is the register-hungry part of a trip; nothing of the LM bookkeeping should
+  // take room in it.
   LmRegs R;
   R.phase = PH_FETCH;
   R.iter = R.evals = R.num_invalid = R.ls_iters = R.n_samples = 0;
   R.status = SMPC_NO_CONVERGENCE; R.reason = SMPC_REASON_MAX_ITERATIONS;
   R.step_successful = R.at_least_one = R.prev_vv = R.prev_gv = R.cur_vv = R.cur_gv = R.first_vv = false;
+  auto park = [&]() {
+    rw[0] = R.iter; rw[1] = R.evals; rw[2] = R.num_invalid; rw[3] = R.ls_iters; rw[4] = R.n_samples; rw[5] = R.status;
+    rw[6] = R.reason;
+    rw[7] = (R.step_successful ? 1 : 0) | (R.at_least_one ? 2 : 0) | (R.prev_vv ? 4 : 0) | (R.prev_gv ? 8 : 0) |
+            (R.cur_vv ? 16 : 0) | (R.cur_gv ? 32 : 0) | (R.first_vv ? 64 : 0);
+  };
+  auto unpark = [&]() {
+    R.iter = rw[0]; R.evals = rw[1]; R.num_invalid = rw[2]; R.ls_iters = rw[3]; R.n_samples = rw[4]; R.status = rw[5];
+    R.reason = rw[6];
+    const int f = rw[7];
+    R.step_successful = f & 1; R.at_least_one = f & 2; R.prev_vv = f & 4; R.prev_gv = f & 8;
+    R.cur_vv = f & 16; R.cur_gv = f & 32; R.first_vv = f & 64;
+  };
   bool ever_loaded = false;
 #ifdef SMPC_STAMPS
   for (int i = 0; i < 8; ++i) c.acc[i] = 0;
@@ -483,6 +509,11 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 
   for (;;) {
     SMPC_STAMP(c, 6);  // LM state machine + output stage of the previous trip
+    {
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      bind(lane_t);
+    }
     // ---------------------------------------------------------------- fetch the next scene for idle slots
     if (R.phase == PH_FETCH) {
       int scene = 0;
@@ -493,7 +524,10 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         ever_loaded = true;
         double v = 0.0;
         if (act) {
-          v = clampd(k.init_params[(size_t)scene * P + q] + 0.0, lo_q, hi_q);  // Plus(x, 0): project the start point (A.4)
+          const bool bnd = (q >> 1) < k.nbounded;
+          const double lo0 = bnd ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
+          const double hi0 = bnd ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
+          v = clampd(k.init_params[(size_t)scene * P + q] + 0.0, lo0, hi0);  // Plus(x, 0): project the start point (A.4)
           xc[q] = v; xt[q] = v;
         }
         double xn, u0, u1;
@@ -516,7 +550,21 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     SMPC_STAMP(c, 0);  // fetch + load_scene
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
-    const GramView GH = sweep<NB, W, false>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    park();
+    sweep<NB, W, false>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    {
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      bind(lane_t);
+    }
+    GramView GH;
+    GH.base = c.lds + c.L.gram;
+    GH.ld = P + 1;
+    unpark();
+    // bounds of parameter q (src/optimizer.cpp:373-379: blocks 0..CH/bl-1 are bounded)
+    const bool bounded = act && (q >> 1) < k.nbounded;
+    const double lo_q = bounded ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
+    const double hi_q = bounded ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
     // usable iff every residual and Jacobian entry was finite: a non-finite one makes its diagonal Gram entry non-finite
     const bool finite = !slot_any(c.sl <= P && !isfinite(GH.base[min(c.sl, P) * GH.ld + min(c.sl, P)]));
     const double val = 0.5 * GH(P, P);
