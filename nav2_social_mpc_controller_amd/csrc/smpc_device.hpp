@@ -68,6 +68,19 @@ struct KParams {
   MathTab mt;  // polynomial coefficients of smpc_math.hpp, read through scalar loads
 };
 
+// Cross-lane sum of the per-lane Gram shares (solve kernel): values go through LDS in chunks of whole columns of the
+// packed upper triangle, at most kGramChunk values at a time; lane (part, v) of a slot then adds up value v of the 16
+// lanes of its part and the parts are combined by shuffles (W / 16 + 3 additions instead of 3 log2(W) shuffle
+// instructions per value). The buffer (W rows of kGramChunk + 1 doubles) lies over the sweep's own temporaries — the
+// cos / sin block and the scans are dead once the sensitivities are formed — plus a tail of its own; outside the
+// sweep the same area holds the temporaries of the LM algebra.
+constexpr int kGramChunk = 16;
+__host__ __device__ constexpr int gram_red_doubles(int W) { return W * (kGramChunk + 1); }
+// doubles of wave-shared LDS behind the per-slot blocks of the solve kernel: the feasibility rows of every slot
+__host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
+  return (kWave / W) * ((P / 2 > 1 ? P / 2 - 1 : 1) * (P + 1));
+}
+
 // LDS carve-up (in doubles) of ONE slot.
 struct LdsLayout {
   int ag;       // [N][T][4]  staged people block (px, py, vx, vy) — staging kernel only; the sweep reads the staged
@@ -95,26 +108,21 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
   L.valid = o; o += T;
   L.cs = o; o += 2 * (T + 1);
   L.inc = o; o += 4 * (T + 1);
+  if (with_lm) {  // tail of the Gram reduction buffer / LM temporaries, which start at L.cs
+    const int W = (T + 1 <= 32 && N <= 32) ? 32 : 64;
+    const int want = gram_red_doubles(W) > P * P + 7 * P + 96 ? gram_red_doubles(W) : P * P + 7 * P + 96;
+    if (want > 6 * (T + 1)) o += want - 6 * (T + 1);
+  }
   L.cst = o; o += 8;
   L.lanec = o; o += 3 * T;
-  L.lm = o; if (with_lm) o += 2 * P * P + 6 * P + 4 * P + 18 * P + 24;  // Hs, Lw, six vectors, hand-over, reductions, scalars
+  L.lm = o; if (with_lm) o += P * P + 6 * P + 24;  // Hs, six vectors, scalars: what lives from trip to trip
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
-  L.scratch = o; if (with_lm) o += 96;  // generic line-search interpolation fallback
+  L.scratch = o;  // (the generic line-search interpolation fallback borrows the wave's Gram reduction buffer)
   L.total = (o + 3) & ~3;  // 32-byte multiple: records are moved as 4-double vectors
   return L;
 }
 
 __host__ __device__ inline int slot_width(int T, int N) { return (T + 1 <= 32 && N <= 32) ? 32 : 64; }
-
-// Cross-lane sum of the per-lane Gram shares (solve kernel): values go through LDS in chunks of whole columns of the
-// packed upper triangle, at most kGramChunk values at a time; lane j of a slot then adds up value j of every lane
-// (W additions instead of 3 log2(W) shuffle instructions per value).
-constexpr int kGramChunk = 16;
-__host__ __device__ constexpr int gram_red_doubles(int W) { return W * (kGramChunk + 1); }
-// doubles of wave-shared LDS behind the per-slot blocks of the solve kernel: reduction buffers + feasibility rows
-__host__ __device__ constexpr int wave_extra_doubles(int P, int W) {
-  return (kWave / W) * (gram_red_doubles(W) + (P / 2 > 1 ? P / 2 - 1 : 1) * (P + 1));
-}
 
 // The workgroup is ONE wavefront: LDS operations of a wave execute in program order, so cross-lane hand-offs through
 // LDS only need the compiler not to reorder them — no s_barrier and, importantly, no s_waitcnt vmcnt(0) that a
@@ -276,6 +284,10 @@ __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux,
   const double cross = fma(ix, ey, -(iy * ex)), dot = fma(ix, ex, iy * ey);
   const bool zero_u = (ux == 0.0) & (uy == 0.0);  // equal velocities: theta := 0 (parity)
   double phi = atan2_dir(mt, cross, dot);
+  // keep the scheduler from interleaving the arctangent, the two exponentials and the derivative block: the extra
+  // overlap buys nothing with two or three waves per SIMD and costs ~15 VGPRs (the stand-alone K1 kernel would drop
+  // from three waves per SIMD to two)
+  __builtin_amdgcn_sched_barrier(0);
   R.special = !zero_u & (fabs(cross) < 1e-6);
   phi = zero_u ? 0.0 : phi;
   const double Bq = gamma * L;  // :203
@@ -284,6 +296,7 @@ __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux,
   const double base = -n * inv_B;
   const double E1 = exp_tab(mt, fma(-a1, a1, base));  // :205-207
   const double E2 = exp_tab(mt, fma(-a2, a2, base));  // :212-215
+  __builtin_amdgcn_sched_barrier(0);
   const double fv = -E1;
   const double fa = (phi > 0.0) ? -E2 : E2;  // -sign(theta) E2, sign = -1 at theta == 0 (:210)
   R.fx = k * (fv * ix - fa * iy);  // :218-224, i_perp = (-iy, ix)
@@ -341,8 +354,7 @@ __device__ inline void cubic_hermite(double p0, double p1, double p2, double p3,
 // cc is then byte (cc - start) of its row's dword — also at the edges, where several taps share a cell.
 struct CostPatch {
   uint32_t row[4];   // bytes start .. start + 3 of the four clamped rows
-  int sh[4];         // bit offset of tap j inside a row dword
-  double tr, tc;     // fractional parts r - floor(r), c - floor(c)
+  uint32_t sh;       // bit offsets (0, 8, 16, 24) of the four taps inside a row dword, 5 bits each
 };
 
 __device__ inline void bicubic_fetch(const uint8_t* __restrict__ map, int size_x, int size_y, double r, double c, CostPatch& p) {
@@ -350,8 +362,10 @@ __device__ inline void bicubic_fetch(const uint8_t* __restrict__ map, int size_x
   const double frc = fmin(fmax(fr, -4.0), (double)size_y + 4.0), fcc = fmin(fmax(fc, -4.0), (double)size_x + 4.0);
   const int row = (int)frc, col = (int)fcc;
   const int start = min(max(col - 1, 0), size_x - 4);
+  uint32_t sh = 0;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) p.sh[j] = 8 * (min(max(col - 1 + j, 0), size_x - 1) - start);
+  for (int j = 0; j < 4; ++j) sh |= (uint32_t)(8 * (min(max(col - 1 + j, 0), size_x - 1) - start)) << (5 * j);
+  p.sh = sh;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rr = min(max(row - 1 + i, 0), size_y - 1);
@@ -359,21 +373,22 @@ __device__ inline void bicubic_fetch(const uint8_t* __restrict__ map, int size_x
     __builtin_memcpy(&v, map + (size_t)rr * size_x + start, 4);  // unaligned dword
     p.row[i] = v;
   }
-  p.tr = r - fr; p.tc = c - fc;
 }
 
-__device__ inline void bicubic_eval(const CostPatch& p, double& f, double& dfdr, double& dfdc) {
+// (r, c) must be the coordinates the patch was fetched for
+__device__ inline void bicubic_eval(const CostPatch& p, double r, double c, double& f, double& dfdr, double& dfdc) {
+  const double tr = r - floor(r), tc = c - floor(c);
   double fv[4], dv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     double t[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = (double)((p.row[i] >> p.sh[j]) & 0xffu);
-    cubic_hermite(t[0], t[1], t[2], t[3], p.tc, fv[i], dv[i]);
+    for (int j = 0; j < 4; ++j) t[j] = (double)((p.row[i] >> ((p.sh >> (5 * j)) & 31u)) & 0xffu);
+    cubic_hermite(t[0], t[1], t[2], t[3], tc, fv[i], dv[i]);
   }
   double unused;
-  cubic_hermite(fv[0], fv[1], fv[2], fv[3], p.tr, f, dfdr);
-  cubic_hermite(dv[0], dv[1], dv[2], dv[3], p.tr, dfdc, unused);
+  cubic_hermite(fv[0], fv[1], fv[2], fv[3], tr, f, dfdr);
+  cubic_hermite(dv[0], dv[1], dv[2], dv[3], tr, dfdc, unused);
 }
 
 __device__ inline void bicubic(const uint8_t* __restrict__ map, int size_x, int size_y, double r, double c,
@@ -640,9 +655,11 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
   // a5 obstacle: the costmap patch under the front point is requested now and used after the agent loop
   const bool wide_map = k.size_x >= 4;
-  const double ob_ic = (X + 0.25 * c1 - cst[4]) / k.resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) / k.resolution;
   CostPatch patch;
-  if (wide_map) bicubic_fetch(c.map, k.size_x, k.size_y, ob_ir, ob_ic, patch);
+  if (wide_map) {
+    const double ob_ic = (X + 0.25 * c1 - cst[4]) / k.resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) / k.resolution;
+    bicubic_fetch(c.map, k.size_x, k.size_y, ob_ir, ob_ic, patch);
+  }
 
   SMPC_STAMP(c, 2);
   // ---- a3 social work + a4 proxemics: walk the agents of step sl
@@ -935,8 +952,10 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   // a5 obstacle
   {
     const double inv_res = 1.0 / k.resolution;
+    // the same expressions as at the fetch (recomputed rather than kept in registers across the agent loop)
+    const double ob_ic = (X + 0.25 * c1 - cst[4]) / k.resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) / k.resolution;
     double f, dfdr, dfdc;
-    if (wide_map) bicubic_eval(patch, f, dfdr, dfdc);
+    if (wide_map) bicubic_eval(patch, ob_ir, ob_ic, f, dfdr, dfdc);
     else bicubic(c.map, k.size_x, k.size_y, ob_ir, ob_ic, f, dfdr, dfdc);  // maps narrower than one patch: byte by byte
     const double r = w.obstacle_w * f;
     const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;
@@ -997,7 +1016,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     }
     // a9 velocity feasibility rows (src/optimizer.cpp:364-370): row q (between blocks q and q-1, 1 <= q <= nfeas) has
     // four non-zero entries; the rows go to LDS as they are and their outer products are added after the lane sum.
-    double* frow = c.wave_lds + (kWave / W) * gram_red_doubles(W) + c.slot * ((NB > 1 ? NB - 1 : 1) * Q);
+    double* frow = c.wave_lds + c.slot * ((NB > 1 ? NB - 1 : 1) * Q);
     if (sl >= 1 && sl <= k.nfeas) {
       const double lin = xp[2 * sl] - xp[2 * sl - 2], ang = xp[2 * sl + 1] - xp[2 * sl - 1];
       const double wf = w.velocity_feasibility_w;
@@ -1008,7 +1027,8 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       fr[2 * sl] = 2.0 * wf * lin; fr[2 * sl + 1] = 2.0 * wf * ang;
       fr[P] = wf * lin * lin + wf * ang * ang;
     }
-    double* red = c.wave_lds + c.slot * gram_red_doubles(W) + sl * (kGramChunk + 1);
+    double* red_base = c.lds + c.L.cs;  // over the cos / sin block and the scans (dead by now) and the tail behind them
+    double* red = red_base + sl * (kGramChunk + 1);
     double hv[kGramChunk];
     int cnt = 0, chunk_base = 0;  // compile-time after unrolling
     auto flush = [&](int n, int base, int col_lo, int col_hi) {
@@ -1021,7 +1041,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       const int vsel = sl & (kGramChunk - 1), part = sl / kGramChunk;
       double tot = 0.0;
       {
-        const double* col = c.wave_lds + c.slot * gram_red_doubles(W) + (part * kGramChunk) * (kGramChunk + 1) + vsel;
+        const double* col = red_base + (part * kGramChunk) * (kGramChunk + 1) + vsel;
 #pragma unroll
         for (int l = 0; l < kGramChunk; ++l) tot += col[l * (kGramChunk + 1)];
       }

@@ -275,6 +275,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
       const int c = std::atoi(cap);
       if (c >= 1 && c < per_cu) per_cu = c;
     }
+    if (std::getenv("SMPC_DEBUG_GRID")) std::fprintf(stderr, "[smpc] solve kernel: %zu B LDS per wave, %d waves per CU\n", shmem, per_cu);
     const int resident = per_cu * h->num_cu;
     if (grid > resident) grid = resident;
     k.queue = h->queue;

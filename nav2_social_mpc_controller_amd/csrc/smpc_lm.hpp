@@ -447,18 +447,20 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     c.lds = lds_all + (size_t)slot * c.L.total;
     c.wave_lds = lds_all + (size_t)S * c.L.total;
     Hs = c.lds + c.L.lm;   // [P][P] scaled J^T J at the current point, dense
-    Lw = Hs + P * P;       // [P][P] rows of the Cholesky factor of the damped system
-    gs = Lw + P * P;       // [P] scaled gradient
+    gs = Hs + P * P;       // [P] scaled gradient
     gu = gs + P;           // [P] unscaled gradient
     xc = gu + P;           // [P] current point
     xt = xc + P;           // [P] trial point (input of the sweep)
     dl = xt + P;           // [P] delta (unscaled step of this iteration)
     sc = dl + P;           // [P] Jacobi scaling
-    bc = sc + P;           // [4][P] hand-over words: pivots, forward / backward solutions, scaled step
-    rs = bc + 4 * P;       // [6][3][P] reduction words, one block per call site
-    sv = rs + 18 * P;      // scalars [24]
+    sv = sc + P;           // scalars [24]
     rw = reinterpret_cast<int32_t*>(sv + S_COUNT);  // the state machine's integers, parked across the sweep
-    scratch = c.lds + c.L.scratch;
+    // temporaries of the LM algebra: over the sweep's cos / sin block, scans and Gram reduction buffer (all dead here)
+    Lw = c.lds + c.L.cs;   // [P][P] rows of the Cholesky factor of the damped system
+    bc = Lw + P * P;       // [4][P] hand-over words: pivots, forward / backward solutions, scaled step
+    rs = bc + 4 * P;       // [3][P] reduction words (every site uses the same three rows: LDS operations of a wave
+                           //        execute in program order, a site's reads are behind it before the next site writes)
+    scratch = rs + 3 * P;  // [96] generic line-search interpolation fallback
     q = c.sl;              // the parameter this lane owns in the LM algebra
     act = q < P;
     qc = act ? q : 0;      // in-range index for lanes that only tag along
@@ -471,7 +473,8 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   // sums / maximum over the parameters: every active lane leaves its terms in the site's words, then every lane adds
   // them up in index order
   auto reduce3 = [&](int site, double a, double b, double m, double& sa, double& sb, double& sm) {
-    double* w3 = rs + site * 3 * P;
+    double* w3 = rs;
+    (void)site;
     if (act) { w3[q] = a; w3[P + q] = b; w3[2 * P + q] = m; }
     wave_lds_fence();
     sa = 0.0; sb = 0.0; sm = 0.0;
