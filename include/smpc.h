@@ -29,7 +29,9 @@ extern "C" {
 #endif
 
 #define SMPC_ABI_VERSION 3
-#define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20 */
+#define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20; every nb in 1..10 is instantiated */
+#define SMPC_MAX_STEPS 63  /* T <= 63: one lane per pose of the rollout (T + 1 poses in a 64-lane wavefront) */
+#define SMPC_MAX_AGENTS 64 /* N <= 64: one bit per agent in the per-step validity mask */
 
 /* linear_solver_type: mirrors OptimizerParams::solver_types (optimizer.hpp:71-77). */
 enum smpc_linear_solver {
@@ -64,7 +66,7 @@ enum smpc_reason {
 enum smpc_error {
   SMPC_OK = 0,
   SMPC_ERR_INVALID_ARG = -1,
-  SMPC_ERR_UNSUPPORTED = -2, /* e.g. nb > SMPC_MAX_BLOCKS */
+  SMPC_ERR_UNSUPPORTED = -2, /* nb > SMPC_MAX_BLOCKS, T > SMPC_MAX_STEPS or N > SMPC_MAX_AGENTS */
   SMPC_ERR_DEVICE = -3,      /* HIP runtime error; see smpc_last_error() */
   SMPC_ERR_NO_DEVICE = -4
 };
@@ -101,7 +103,10 @@ typedef struct smpc_params {
 /* Fill with the reference's code defaults (src/optimizer.cpp:26-82) and hard-coded literals. */
 void smpc_params_default(smpc_params* p);
 
-/* One batch of independent scenes. All scenes share T, N, dt, costmap geometry. */
+/* One batch of independent scenes. All scenes share T, N, dt, costmap geometry.
+ * Row layout of every scene: 8 rows per step when the scene has people, 5 when it has none (has_people[i] == 0),
+ * plus the feasibility rows; output arrays of smpc_eval_batch are always strided by M = 8 T + n_feasibility (the
+ * with-people size, whatever has_people says), rows a scene does not have are written as zeros. */
 typedef struct smpc_scene_batch {
   int32_t B;         /* scenes */
   int32_t T;         /* rollout steps */

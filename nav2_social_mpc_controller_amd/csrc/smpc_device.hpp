@@ -1062,7 +1062,6 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     int col_lo = 0;
 #pragma unroll
     for (int bq = 0; bq < Q; ++bq) {  // column bq of [J r]: 2q = v_q, 2q+1 = w_q, P = r
-      if (cnt + bq + 1 > kGramChunk) { flush(cnt, chunk_base, col_lo, bq - 1); chunk_base += cnt; cnt = 0; col_lo = bq; }
       double Wx, Wy, Wt, Wv;  // column bq of A M (for bq = P: b itself)
       if (bq == P) { Wx = bx; Wy = by; Wt = bt; Wv = bv; }
       else if ((bq & 1) == 0) {
@@ -1091,10 +1090,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
           const int q = aq >> 1;
           h = fma(Sxw[q], Wx, fma(Syw[q], Wy, Sthw[q] * Wt));
         }
+        if (cnt == 0) col_lo = bq;
         hv[cnt++] = h;
+        if (cnt == kGramChunk) { flush(cnt, chunk_base, col_lo, bq); chunk_base += cnt; cnt = 0; }  // a full chunk
       }
     }
-    flush(cnt, chunk_base, col_lo, P);
+    if (cnt > 0) flush(cnt, chunk_base, col_lo, P);
   }
   wave_lds_fence();  // Gram visible to every lane of the slot; the cos/sin block may be rewritten by the next sweep
   SMPC_STAMP(c, 5);

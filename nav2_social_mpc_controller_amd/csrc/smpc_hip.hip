@@ -127,6 +127,10 @@ KernelFn pick(int nb, int W, bool eval) {
     case 4: return pick_w<4>(W, eval);
     case 5: return pick_w<5>(W, eval);
     case 6: return pick_w<6>(W, eval);
+    case 7: return pick_w<7>(W, eval);
+    case 8: return pick_w<8>(W, eval);
+    case 9: return pick_w<9>(W, eval);
+    case 10: return pick_w<10>(W, eval);
     default: return nullptr;
   }
 }
@@ -142,7 +146,7 @@ int validate(const smpc_handle* h, const smpc_scene_batch* sb, Dims* d) {
   *d = make_dims(h->prm, sb->T, true);
   if (sb->T + 1 > smpc::kWave) { set_error("T + 1 > 64 rollout poses is not supported by the one-wave-per-scene mapping"); return SMPC_ERR_UNSUPPORTED; }
   if (sb->N > smpc::kWave) { set_error("N > 64 agents is not supported"); return SMPC_ERR_UNSUPPORTED; }
-  if (!pick(d->nb, 64, false)) { set_error("number of parameter blocks not instantiated (nb must be 1..6)"); return SMPC_ERR_UNSUPPORTED; }
+  if (!pick(d->nb, 64, false)) { set_error("more than SMPC_MAX_BLOCKS parameter blocks (nb must be 1..10)"); return SMPC_ERR_UNSUPPORTED; }
   return SMPC_OK;
 }
 
@@ -277,7 +281,12 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     }
     if (std::getenv("SMPC_DEBUG_GRID")) std::fprintf(stderr, "[smpc] solve kernel: %zu B LDS per wave, %d waves per CU\n", shmem, per_cu);
     const int resident = per_cu * h->num_cu;
-    if (grid > resident) grid = resident;
+    // A launch alone on the GPU finishes soonest with two waves per SIMD (two scenes per slot at the headline batch:
+    // a third wave per SIMD lengthens every trip more than it shortens the queue, and the tail of long scenes grows);
+    // the third wave's registers and LDS then stay free for the launches of other streams, which is where the extra
+    // occupancy pays. Only a batch with many scenes per slot takes every resident wave for itself.
+    const int two_per_simd = 8 * h->num_cu < resident ? 8 * h->num_cu : resident;
+    if (grid > two_per_simd) grid = (grid >= 4 * resident) ? resident : two_per_simd;
     k.queue = h->queue;
     SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
   }

@@ -114,3 +114,17 @@ def test_create_fails_loudly_without_a_gpu():
     from nav2_social_mpc_controller_amd.params import OptimizerParams
     with pytest.raises(S.SmpcError, match="no HIP device|hip"):
         S.BatchSolver(OptimizerParams.readme())
+
+
+def test_block_limit_matches_the_header():
+    """smpc_dims reports nb for any shape; the header's SMPC_MAX_BLOCKS is what the library instantiates (nb 1..10)."""
+    lib = S.load_library()
+    src = open(HEADER).read()
+    assert int(re.search(r"#define SMPC_MAX_BLOCKS (\d+)", src).group(1)) == 10
+    p = _abi.SmpcParams()
+    lib.smpc_params_default(C.byref(p))
+    nb = C.c_int()
+    p.control_horizon, p.parameter_block_length = 33, 3
+    assert lib.smpc_dims(C.byref(p), 40, 1, None, None, C.byref(nb), None, None, None) == 0 and nb.value == 11
+    hip_src = open(os.path.join(ROOT, "nav2_social_mpc_controller_amd", "csrc", "smpc_hip.hip")).read()
+    assert "case 10: return pick_w<10>" in hip_src and "case 11" not in hip_src

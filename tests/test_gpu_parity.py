@@ -45,6 +45,9 @@ EVAL_CASES = {
     # T=28 (two scenes per wave) with 5 parameter blocks: [J r] has 11 columns -> VALU Gram back-end instead of MFMA
     "w32_five_blocks_valu_gram": (README.replace(parameter_block_length=4), dict(B=32, N=6, seed=110)),
     "six_blocks": (README.replace(parameter_block_length=3), dict(B=16, N=4, seed=111)),
+    # up to SMPC_MAX_BLOCKS = 10 parameter blocks (P = 20): control_horizon 30 over T = 38
+    "eight_blocks": (README.replace(control_horizon=30, parameter_block_length=4, max_time=2.0), dict(B=8, N=4, seed=118)),
+    "ten_blocks": (README.replace(control_horizon=30, parameter_block_length=3, max_time=2.0), dict(B=8, N=4, seed=119)),
     # the largest supported shape: T = 63 rollout steps (max_time 3.25 s), 64 agents (K1 stages 129 KB of people in LDS)
     "max_T63_N64": (README.replace(max_time=3.25), dict(B=4, N=64, seed=112, map_cells=120)),
     "n33_needs_wide_slot": (README, dict(B=6, N=33, seed=113, map_cells=120)),
@@ -115,6 +118,8 @@ SOLVE_CASES = {
     "quirk_bl_not_dividing_ch": (README.replace(time_step=0.1), dict(B=128, N=3, seed=207)),
     "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=64, N=5, seed=209)),
     "w32_five_blocks_valu_gram": (README.replace(parameter_block_length=4), dict(B=128, N=6, seed=210)),
+    "eight_blocks": (README.replace(control_horizon=30, parameter_block_length=4, max_time=2.0), dict(B=48, N=4, seed=218)),
+    "ten_blocks": (README.replace(control_horizon=30, parameter_block_length=3, max_time=2.0), dict(B=48, N=4, seed=219)),
     "max_T63_N64": (README.replace(max_time=3.25), dict(B=24, N=64, seed=212, map_cells=120)),
     "t31_last_two_slot_shape": (README.replace(max_time=1.65), dict(B=48, N=5, seed=214, map_cells=100)),
     "t32_first_one_slot_shape": (README.replace(max_time=1.70), dict(B=48, N=5, seed=215, map_cells=100)),
