@@ -60,7 +60,7 @@ __global__ void smpc_math_probe_kernel(const ProbeParams) {
   const auto& k = *(const ProbeParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k.n) return;
-  const double a = k.a[i], b = k.b ? k.b[i] : 0.0;
+  const double a = (k.fn == 7) ? 0.0 : k.a[i], b = k.b ? k.b[i] : 0.0;
   double r0 = 0.0, r1 = 0.0;
   switch (k.fn) {
     case 0: r0 = exp_tab(&k.mt, a); break;
@@ -69,6 +69,13 @@ __global__ void smpc_math_probe_kernel(const ProbeParams) {
     case 3: r0 = rsqrt_pos(a); break;
     case 4: r0 = div_fast(a, b); break;
     case 5: r0 = rcp_estimate(a); break;
+    case 7: {  // a = [c4 c3 c2 c1 c0 lo hi _] per problem: the line search's bracketed root finder, trips in out1
+      const double q[5] = {k.a[8 * i], k.a[8 * i + 1], k.a[8 * i + 2], k.a[8 * i + 3], k.a[8 * i + 4]};
+      int trips = 0;
+      r0 = bracketed_root<4>(q, k.a[8 * i + 5], k.a[8 * i + 6], &trips);
+      r1 = (double)trips;
+      break;
+    }
     default: r0 = rsq_estimate(a); break;
   }
   k.o0[i] = r0;
@@ -315,6 +322,12 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * tot[i] / all);
     std::fprintf(stderr, " | rows split: people-critics=%.1f%% vel/goal/dist=%.1f%% obstacle=%.1f%% (rest of rows = feas + gram out)\n",
                  100.0 * tot[8] / all, 100.0 * tot[9] / all, 100.0 * tot[10] / all);
+    if (!eval) {
+      unsigned long long dbg[8] = {0};
+      (void)hipMemcpyFromSymbol(dbg, HIP_SYMBOL(smpc::g_ls_dbg), sizeof(dbg));
+      std::fprintf(stderr, "[ls counters, cumulative] root4 calls %llu trips %llu | root3 calls %llu trips %llu | cubic fits %llu quintic fits %llu "
+                   "(monotone shortcut %llu) generic fallback %llu\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]);
+    }
   }
 #endif
   return SMPC_OK;
@@ -810,7 +823,7 @@ double smpc_fp64_peak_probe(smpc_handle* h, int32_t iters) {
 }
 
 int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1) {
-  if (!h || !a || !out0 || n < 0 || fn < 0 || fn > 6) { set_error("bad arguments to smpc_math_probe"); return SMPC_ERR_INVALID_ARG; }
+  if (!h || !a || !out0 || n < 0 || fn < 0 || fn > 7) { set_error("bad arguments to smpc_math_probe"); return SMPC_ERR_INVALID_ARG; }
   if ((fn == 1 || fn == 4) && !b) { set_error("second argument array is null"); return SMPC_ERR_INVALID_ARG; }
   if (fn == 2 && !out1) { set_error("out1 is null for sincos"); return SMPC_ERR_INVALID_ARG; }
   SMPC_HIP_CHECK(hipSetDevice(h->device));
@@ -819,7 +832,7 @@ int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, cons
   p.fn = fn; p.n = n;
   smpc::fill_math_table(&p.mt);
   Staging st(h);
-  SMPC_TRY(st.up(a, (size_t)n, &p.a, h->stream));
+  SMPC_TRY(st.up(a, (size_t)n * (fn == 7 ? 8 : 1), &p.a, h->stream));
   SMPC_TRY(st.up(b, (size_t)n, &p.b, h->stream));
   SMPC_TRY(st.out(out0, (size_t)n, &p.o0));
   SMPC_TRY(st.out(out1, (size_t)n, &p.o1));

@@ -13,6 +13,15 @@
 
 namespace smpc {
 
+#ifdef SMPC_STAMPS
+// diagnostic build only: [0] bracketed_root<4> calls, [1] their iterations, [2] bracketed_root<3> calls, [3] iterations,
+// [4] interpolations (cubic), [5] (quintic), [6] quintic shortcut taken, [7] generic fallback
+__device__ unsigned long long g_ls_dbg[8];
+#define SMPC_LS_COUNT(i, n) do { if ((threadIdx.x & 31) == 0) atomicAdd(&g_ls_dbg[i], (unsigned long long)(n)); } while (0)
+#else
+#define SMPC_LS_COUNT(i, n) do { } while (0)
+#endif
+
 // ---- small uniform helpers working on an LDS scratch area (dynamic indexing without private scratch) ----
 
 // Solve A z = b with full pivoting, n <= 6, A row-major n x n in LDS (destroyed). Result in z (LDS).
@@ -219,7 +228,7 @@ template <int D> __device__ inline void horner_d(const double (&p)[D + 1], doubl
 
 // The root of p inside [a, b], a <= b, given that p is monotone there: Newton from the midpoint, kept inside the
 // shrinking sign-change bracket (bisection whenever a Newton step leaves it). NaN if p does not change sign on [a, b].
-template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1], double a, double b) {
+template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1], double a, double b, int* trips = nullptr) {
   double fa, fb, t;
   horner_d<D>(p, a, fa, t);
   horner_d<D>(p, b, fb, t);
@@ -232,12 +241,17 @@ template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1
   double xl = a, xh = b, x = a - fa * (b - a) * fast_rcp(fb - fa);
   if (!(x > a && x < b)) x = 0.5 * (a + b);
   for (int it = 0; it < 80; ++it) {
+    SMPC_LS_COUNT(D == 4 ? 1 : 3, 1);
+    if (trips) ++*trips;
     double fx, dfx;
     horner_d<D>(p, x, fx, dfx);
     if (fx == 0.0) break;
     if ((fx < 0.0) == neg_lo) xl = x; else xh = x;
     double xn = x - fx * fast_rcp(dfx);
-    const bool newton = xn > xl && xn < xh;
+    // inclusive: a converged iterate moves by less than an ulp, lands ON the bracket end it has just become, and must
+    // count as a (zero-length) Newton step — with strict inequalities it was sent back to the midpoint of a still wide
+    // bracket and the search started over (measured on real line searches: 11 % of the calls took 16..58 trips)
+    const bool newton = xn >= xl && xn <= xh;
     if (!newton) xn = 0.5 * (xl + xh);
     // A Newton step below 1e-9 |x| leaves an error of the order of its square; waiting for the step itself to reach
     // round-off would spin on polynomials whose Horner value is noisier than that (measured: 7% of the solve kernel).
@@ -246,6 +260,7 @@ template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1
     x = xn;
     if (done) break;
   }
+  SMPC_LS_COUNT(D == 4 ? 0 : 2, 1);
   return x;
 }
 
@@ -276,6 +291,7 @@ __device__ inline void quartic_roots_in_range_lanes(const double (&q)[5], double
     horner_d<3>(d1, lo, va, t); horner_d<3>(d1, hi, vb, t); horner_d<3>(d1, e0, vc, t); horner_d<3>(d1, e1, vd, t);
     const double mn = fmin(fmin(va, vb), fmin(vc, vd)), mx = fmax(fmax(va, vb), fmax(vc, vd));
     const bool one_sign = (mn > 0.0) || (mx < 0.0);
+    if (one_sign) SMPC_LS_COUNT(6, 1);
     if (one_sign) {  // decided per slot (the value is the same in all its lanes): a result never depends on the wave's other scene
       const double root = bracketed_root<4>(q, lo, hi);
       roots[0] = root;
@@ -310,6 +326,7 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
   if (use_prev && !previous.gradient_valid) return false;
   const double f0 = lower.value, g0 = lower.gradient;
   double opt_x = (lo + hi) / 2.0, opt_v;
+  SMPC_LS_COUNT(use_prev ? 5 : 4, 1);
   if (!use_prev) {
     constexpr int nc = 4;
     // a x1^3 + b x1^2 = f1 - g0 x1 - f0 =: A ;  3 a x1^2 + 2 b x1 = g1 - g0 =: B, solved in closed form (the reference
@@ -660,7 +677,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
           Sample current{alpha, val, gd, R.cur_vv, R.cur_gv};
           SMPC_STAMP(c, 6);
           if (!interpolate_step_fast(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, step_size))
-            step_size = interpolate_step(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, scratch);
+          { SMPC_LS_COUNT(7, 1); step_size = interpolate_step(lower, previous, current, 1e-3 * alpha, 0.6 * alpha, scratch); }
           SMPC_STAMP(c, 7);  // line-search interpolation
           failed = step_size * sv[S_DIRMAX] < 1e-9;
         }

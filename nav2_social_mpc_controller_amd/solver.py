@@ -119,7 +119,7 @@ class BatchSolver:
     def math_probe(self, fn: int, a: np.ndarray, b: np.ndarray = None):
         """smpc_math_probe: the sweep's elementary functions evaluated on the device (see include/smpc.h)."""
         a = np.ascontiguousarray(a, dtype=np.float64)
-        n = a.size
+        n = a.size // 8 if fn == 7 else a.size
         bb = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
         o0 = np.empty(n)
         o1 = np.empty(n)
