@@ -125,3 +125,29 @@ def test_episode_with_trajectorizer_matches_cpu_chain(oracle):
         assert firm.mean() >= 0.8 and np.max(err[firm]) <= CMD_TOL, (tick, float(np.max(err[firm])))
     assert np.max(np.abs(ep.pose.cpu().numpy()[:, :2] - sc.pose0[:, :2])) > 0.02
     assert 0 < seen < 3 * B * 2   # the filter kept some persons and dropped some
+
+
+@pytest.mark.gpu
+def test_short_plans_fall_back_to_the_trajectorizer_command():
+    """A documented limit of the fixed-T batch: a robot whose trajectorized path has fewer than T + 1
+    poses (it reaches the end of its plan inside the horizon) gets the trajectorizer's first command, source = 1 —
+    where the reference would run the MPC on the shorter horizon. Counted here so that the limit stays visible."""
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode, arc_plans
+    from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
+    from nav2_social_mpc_controller_amd.scenes import make_scenes, uniform
+
+    prm = OptimizerParams.readme()
+    tp = TrajectorizerParams(desired_linear_vel=0.6, lookahead_dist=0.4, max_angular_vel=1.0, time_step=0.05, max_time=1.5)
+    B, N = 32, 3
+    sc = make_scenes(prm, B, N, n_valid=2)
+    w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
+    long_plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)
+    short = np.arange(B) % 2 == 1
+    plan_len = np.where(short, 12, plan_len).astype(np.int32)     # 12 poses x 0.05 m = 0.55 m: reached in < T steps
+    ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)),
+                      plan=long_plan, plan_len=plan_len, traj_params=tp, fov_angle=1.2)
+    r = ep.tick(record=True)
+    src = ep.cmd_source.cpu().numpy()
+    assert (r.traj_n_poses[short] < sc.T + 1).all() and (r.traj_n_poses[~short] == tp.max_steps + 1).all()
+    assert (src[short] == 1).all() and (src[~short] == 0).all()
+    assert np.array_equal(ep.cmd_vel.cpu().numpy()[short], r.plan_cmds[short, 0])
