@@ -503,6 +503,7 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
   int G = 2;
   while (G < in->N + 1) G *= 2;
   p.G = G;
+  smpc::fill_math_table(&p.mt);
   p.max_time = in->max_time; p.time_step = in->time_step; p.od_resolution = in->od_resolution;
   p.od_shared = in->od_shared; p.od_width = in->od_width; p.od_height = in->od_height;
   const size_t B = in->B, T = in->T, N = in->N;

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/smpc.h"
+#include "smpc_math.hpp"
 
 namespace smpc {
 
@@ -22,6 +23,7 @@ struct ProjParams {
   const double* od_origin;
   double* people_proj;
   int32_t* error;
+  MathTab mt;  // polynomial tables of smpc_math.hpp (scalar loads, see there)
 };
 
 // The reference normalises angles by repeated +-2 pi (sfm angle.hpp); every argument on this path is a difference of
@@ -37,7 +39,8 @@ __device__ inline double proj_wrap(double a) {
 
 // computeObstacle (src/optimizer.cpp:673-728): nearest-obstacle lookup, float arithmetic as in the reference;
 // returns agent - obstacle (the reference stores this DIFFERENCE where the SFM expects a position).
-__device__ inline int proj_obstacle(const ProjParams& p, const uint32_t* idx, double ox, double oy, double px, double py,
+template <typename PP>
+__device__ inline int proj_obstacle(const PP& p, const uint32_t* idx, double ox, double oy, double px, double py,
                                     double& dx, double& dy) {
   const double res = (double)p.od_resolution;
   const unsigned int xcell = (unsigned int)(long long)floor((px - ox) / res);
@@ -53,7 +56,12 @@ __device__ inline int proj_obstacle(const ProjParams& p, const uint32_t* idx, do
   return SMPC_PROJ_OK;
 }
 
-__global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
+// sqrt(z) for z >= 0 through the refined reciprocal square root (1-2 ulp; 0 stays 0)
+__device__ inline double proj_sqrt(double z) { return z > 0.0 ? z * rsqrt_pos(z) : 0.0; }
+
+__global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
+  const auto& p = *(const ProjParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  const MathTabP mt = &p.mt;
   const int lane = threadIdx.x & 63;
   const int G = p.G, T = p.T, N = p.N;
   const int grp = lane / G, g = lane - grp * G, base = grp * G;
@@ -111,10 +119,11 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
     double fx, fy;
     {
       const double ddx = gx - px, ddy = gy - py;
-      const double dn = sqrt(ddx * ddx + ddy * ddy);
+      const double z = ddx * ddx + ddy * ddy;
+      const double inv = rsqrt_pos(fmax(z, 1e-300));
+      const double dn = z * inv;
       if (has_goal && dn > grad) {  // computeDesiredForce :188-205
-        const double z = ddx * ddx + ddy * ddy;
-        const double ux = z > 0 ? ddx / sqrt(z) : ddx, uy = z > 0 ? ddy / sqrt(z) : ddy;
+        const double ux = z > 0 ? ddx * inv : ddx, uy = z > 0 ? ddy * inv : ddy;
         fx = kFd * (ux * des - vx) / kRelax;
         fy = kFd * (uy * des - vy) / kRelax;
       } else {
@@ -125,10 +134,11 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
     if (is_agent) {  // computeObstacleForce :207-235, one obstacle entry, used as a POSITION
       const double mx = px - obx, my = py - oby;
       const double z = mx * mx + my * my;
-      const double mn = sqrt(z);
-      const double e = kFo * exp(-(mn - radius) / kSig);
-      fx += e * (z > 0 ? mx / mn : mx);
-      fy += e * (z > 0 ? my / mn : my);
+      const double inv = rsqrt_pos(fmax(z, 1e-300));
+      const double mn = z * inv;
+      const double e = kFo * exp_tab(mt, -(mn - radius) * (1.0 / kSig));
+      fx += e * (z > 0 ? mx * inv : mx);
+      fy += e * (z > 0 ? my * inv : my);
     }
     // computeSocialForce(index, agents) :237-281. The force on i from j is the exact negative of the force on j from i
     // (diff, velocity difference and with them the interaction vector flip sign; theta, B and both exponentials are
@@ -141,19 +151,28 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
       const double wx = __shfl(vx, base + j, 64), wy = __shfl(vy, base + j, 64);
       const double dfx = qx - px, dfy = qy - py;
       const double z = dfx * dfx + dfy * dfy;
-      const double nd = sqrt(z);
-      const double ex = z > 0 ? dfx / nd : dfx, ey = z > 0 ? dfy / nd : dfy;
+      const double inv_nd = rsqrt_pos(fmax(z, 1e-300));
+      const double nd = z * inv_nd;
+      const double ex = z > 0 ? dfx * inv_nd : dfx, ey = z > 0 ? dfy * inv_nd : dfy;
       const double ivx = kLam * (vx - wx) + ex, ivy = kLam * (vy - wy) + ey;
-      const double il = sqrt(ivx * ivx + ivy * ivy);
-      const double ix = ivx / il, iy = ivy / il;
+      const double inv_il = rsqrt_pos(ivx * ivx + ivy * ivy);
+      const double il = (ivx * ivx + ivy * ivy) * inv_il;
+      const double ix = ivx * inv_il, iy = ivy * inv_il;
       // equal velocities (two standing people): theta is mathematically 0 and the reference gets its libm's last-bit
       // noise (its thetaSign is then 0 or +-1 by chance); take exactly 0, the convention of the hot path
       const bool same_vel = (kLam * (vx - wx) == 0.0) && (kLam * (vy - wy) == 0.0);
-      const double theta = same_vel ? 0.0 : proj_wrap(proj_wrap(atan2(ey, ex)) - proj_wrap(atan2(iy, ix)));
+      // theta = wrap(atan2(e) - atan2(i)) is the angle from i to e = atan2(i x e, i . e): one table arctangent away from
+      // theta = 0 and |theta| = pi, the reference's own two-atan2 form next to them (its last bits decide thetaSign)
+      const double cross = ix * ey - iy * ex, dot = ix * ex + iy * ey;
+      double theta = atan2_dir(mt, cross, dot);
+      if (!(fabs(cross) >= 1e-6)) theta = proj_wrap(proj_wrap(atan2(ey, ex)) - proj_wrap(atan2(iy, ix)));
+      theta = same_vel ? 0.0 : theta;
       const double Bq = kGam * il;
-      const double fv = -exp(-nd / Bq - (kNp * Bq * theta) * (kNp * Bq * theta));
+      const double earg = -nd * inv_il * (1.0 / kGam);  // -|diff| / B
+      const double a1 = kNp * Bq * theta, a2 = kN * Bq * theta;
+      const double fv = -exp_tab(mt, fma(-a1, a1, earg));
       const double sgn = (theta == 0) ? 0.0 : ((theta > 0) ? 1.0 : -1.0);  // sfm.hpp:265-270
-      const double fa = -sgn * exp(-nd / Bq - (kN * Bq * theta) * (kN * Bq * theta));
+      const double fa = -sgn * exp_tab(mt, fma(-a2, a2, earg));
       const double sfx = kFs * (fv * ix + fa * (-iy));
       const double sfy = kFs * (fv * iy + fa * ix);
       const bool act = g < n_act;
@@ -168,17 +187,18 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams p) {
     vx += fx * dt; vy += fy * dt;
     {
       const double z = vx * vx + vy * vy;
-      const double sp = sqrt(z);
-      if (sp > des) { vx = (z > 0 ? vx / sp : vx) * des; vy = (z > 0 ? vy / sp : vy) * des; }
+      const double inv = rsqrt_pos(fmax(z, 1e-300));
+      const double sp = z * inv;
+      if (sp > des) { vx = (z > 0 ? vx * inv : vx) * des; vy = (z > 0 ? vy * inv : vy) * des; }
     }
     const double init_yaw = yaw;
     yaw = proj_wrap(atan2(vy, vx));
     av = proj_wrap(yaw - init_yaw) / dt;
     px += vx * dt; py += vy * dt;
-    lv = sqrt(vx * vx + vy * vy);
+    lv = proj_sqrt(vx * vx + vy * vy);
     if (has_goal) {
       const double ddx = gx - px, ddy = gy - py;
-      if (sqrt(ddx * ddx + ddy * ddy) <= grad) has_goal = false;
+      if (proj_sqrt(ddx * ddx + ddy * ddy) <= grad) has_goal = false;
     }
     // ---- refresh each person's obstacle entry (:636-640) and emit people_traj[i+1] (:642-668)
     if (is_agent) {
