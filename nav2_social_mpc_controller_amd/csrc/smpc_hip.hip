@@ -696,6 +696,7 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
   p.B = in->B; p.L = in->L; p.max_steps = in->max_steps; p.omnidirectional = in->omnidirectional;
   p.desired_linear_vel = in->desired_linear_vel; p.lookahead_dist = in->lookahead_dist;
   p.max_angular_vel = in->max_angular_vel; p.time_step = in->time_step;
+  smpc::fill_math_table(&p.mt);
   Staging st(h);
   if (in->on_device) {
     p.plan = in->plan; p.plan_len = in->plan_len; p.robot_pose = in->robot_pose;
@@ -712,8 +713,28 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
   }
   if (B > 0) {
     const int per_wave = smpc::kWave / smpc::kTrajGroup;
+    // plans of up to 512 poses stay in registers (kR poses per lane of a 16-lane group); the raw step outputs are parked
+    // in LDS (48 bytes per step and plan): four-wavefront blocks while their park fits in 48 KB (64 steps), else
+    // one-wavefront blocks (up to 256 steps). Longer plans / horizons take the kernel that searches the plan in memory.
+    const size_t park_step = (size_t)smpc::kTrajParkDoubles * sizeof(double);
+    const size_t park_wave = (size_t)per_wave * in->max_steps * park_step;
+    const int threads = (park_wave * (smpc::kTrajBlock / smpc::kWave) <= 48 * 1024) ? smpc::kTrajBlock : smpc::kWave;
+    const int per_block = threads / smpc::kTrajGroup;
+    const size_t park = park_wave * (threads / smpc::kWave);
+    const dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(threads);
+    const int need = (int)((L + smpc::kTrajGroup - 1) / smpc::kTrajGroup);
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel, dim3((unsigned)((B + per_wave - 1) / per_wave)), dim3(smpc::kWave), 0, h->stream, p);
+    if (need > 32 || park > 48 * 1024) {
+      hipLaunchKernelGGL(smpc::smpc_trajectorize_long_kernel, dim3((unsigned)((B + per_wave - 1) / per_wave)), dim3(smpc::kWave), 0, h->stream, p);
+    } else if (need <= 8) {
+      hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel<8>, grid, block, park, h->stream, p);
+    } else if (need <= 16) {
+      hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel<16>, grid, block, park, h->stream, p);
+    } else if (need <= 25) {
+      hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel<25>, grid, block, park, h->stream, p);
+    } else {
+      hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel<32>, grid, block, park, h->stream, p);
+    }
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;

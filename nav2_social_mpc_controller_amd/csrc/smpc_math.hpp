@@ -137,7 +137,10 @@ SMPC_MATH_FN double atan2_dir(MathTabP t, double y, double x) {
 // sin and cos of theta for |theta| <= 1e5 (headings of a rollout: yaw0 + sum of bounded angular steps); the caller
 // falls back to the library routine beyond that. Two-part Cody-Waite reduction with fused multiply-adds (the first
 // product k * pio2_hi is exact inside the fma), minimax kernels on [-pi/4, pi/4], quadrant by bit tricks.
-SMPC_MATH_FN void sincos_tab(MathTabP t, double theta, double* sn, double* cs) {
+// (TabP: any pointer to a table with sin_c / cos_c / two_over_pi / pio2_hi / pio2_lo: the kernel-argument MathTab, or
+// a copy a kernel keeps in registers across a loop.)
+template <class TabP>
+SMPC_MATH_FN void sincos_tab(TabP t, double theta, double* sn, double* cs) {
   const double kf = __builtin_rint(theta * t->two_over_pi);
   double r = fma(-kf, t->pio2_hi, theta);
   r = fma(-kf, t->pio2_lo, r);

@@ -59,6 +59,49 @@ __device__ inline int proj_obstacle(const PP& p, const uint32_t* idx, double ox,
 // sqrt(z) for z >= 0 through the refined reciprocal square root (1-2 ulp; 0 stays 0)
 __device__ inline double proj_sqrt(double z) { return z > 0.0 ? z * rsqrt_pos(z) : 0.0; }
 
+// computeSocialForce's term of one partner (sfm.hpp:237-281): diff = partner - self, dv = own velocity - partner's.
+// Constants of the reference's defaults (forceFactorSocial 2.1, lambda 2, gamma 0.35, n 2, n' 3). Two phases, so that
+// a caller with several partners in flight keeps their arithmetic in straight-line code and visits the rare
+// two-arctangent form once for all of them.
+struct ProjPair {
+  double ex, ey, ix, iy, il, earg, theta;
+  bool same_vel, near_axis;
+};
+__device__ inline void proj_pair_begin(MathTabP mt, double dfx, double dfy, double dvx, double dvy, ProjPair& q) {
+  const double kLam = 2.0, kGam = 0.35;
+  const double z = dfx * dfx + dfy * dfy;
+  const double inv_nd = rsqrt_pos(fmax(z, 1e-300));
+  const double nd = z * inv_nd;
+  q.ex = z > 0 ? dfx * inv_nd : dfx; q.ey = z > 0 ? dfy * inv_nd : dfy;
+  const double ivx = kLam * dvx + q.ex, ivy = kLam * dvy + q.ey;
+  const double inv_il = rsqrt_pos(ivx * ivx + ivy * ivy);
+  q.il = (ivx * ivx + ivy * ivy) * inv_il;
+  q.ix = ivx * inv_il; q.iy = ivy * inv_il;
+  // equal velocities (two standing people): theta is mathematically 0 and the reference gets its libm's last-bit
+  // noise (its thetaSign is then 0 or +-1 by chance); take exactly 0, the convention of the hot path
+  q.same_vel = (kLam * dvx == 0.0) && (kLam * dvy == 0.0);
+  // theta = wrap(atan2(e) - atan2(i)) is the angle from i to e = atan2(i x e, i . e): one table arctangent away from
+  // theta = 0 and |theta| = pi, the reference's own two-atan2 form next to them (its last bits decide thetaSign)
+  const double cross = q.ix * q.ey - q.iy * q.ex, dot = q.ix * q.ex + q.iy * q.ey;
+  q.theta = atan2_dir(mt, cross, dot);
+  q.near_axis = !q.same_vel && !(fabs(cross) >= 1e-6);  // (equal velocities: i = e, cross = 0, theta := 0 anyway)
+  q.earg = -nd * inv_il * (1.0 / kGam);  // -|diff| / B
+}
+__device__ inline void proj_pair_exact_theta(ProjPair& q) {
+  if (q.near_axis) q.theta = proj_wrap(proj_wrap(atan2(q.ey, q.ex)) - proj_wrap(atan2(q.iy, q.ix)));
+}
+__device__ inline void proj_pair_end(MathTabP mt, const ProjPair& q, double& sfx, double& sfy) {
+  const double kFs = 2.1, kGam = 0.35, kN = 2.0, kNp = 3.0;
+  const double theta = q.same_vel ? 0.0 : q.theta;
+  const double Bq = kGam * q.il;
+  const double a1 = kNp * Bq * theta, a2 = kN * Bq * theta;
+  const double fv = -exp_tab(mt, fma(-a1, a1, q.earg));
+  const double sgn = (theta == 0) ? 0.0 : ((theta > 0) ? 1.0 : -1.0);  // sfm.hpp:265-270
+  const double fa = -sgn * exp_tab(mt, fma(-a2, a2, q.earg));
+  sfx = kFs * (fv * q.ix + fa * (-q.iy));
+  sfy = kFs * (fv * q.iy + fa * q.ix);
+}
+
 __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
   const auto& p = *(const ProjParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const MathTabP mt = &p.mt;
@@ -75,7 +118,7 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
   double* out = p.people_proj + s * (size_t)(T + 1) * 6 * N;
   const double dt = (double)p.time_step;
   const bool grid_not_valid = (p.od_width == 100 && p.od_height == 100);  // src/optimizer.cpp:598-603
-  const double kFd = 2.0, kFo = 20.0, kSig = 0.2, kFs = 2.1, kLam = 2.0, kGam = 0.35, kN = 2.0, kNp = 3.0, kRelax = 0.5;
+  const double kFd = 2.0, kFo = 20.0, kSig = 0.2, kRelax = 0.5;
 
   // people_traj[0] = init_people
   if (live_scene)
@@ -110,7 +153,8 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
       const double* r = rpath + (size_t)i * 6;
       px = r[0]; py = r[1]; yaw = r[2]; lv = r[4]; av = r[5];
       double sn, cs;
-      sincos(yaw, &sn, &cs);
+      if (__builtin_expect(!(fabs(yaw) <= 1e5), 0)) sincos(yaw, &sn, &cs);
+      else sincos_tab(mt, yaw, &sn, &cs);
       vx = lv * cs; vy = lv * sn;
       des = 0.6; radius = 0.5;
       gx = rpath[(size_t)T * 6]; gy = rpath[(size_t)T * 6 + 1]; has_goal = true;
@@ -145,42 +189,39 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
     // unchanged), so every unordered pair is evaluated once: in round k lane i takes partner (i + k) mod n and hands the
     // negated force to it by shuffle; for even n the last round (k = n/2) pairs lanes mutually and needs no hand-over.
     // The sum over partners runs in round order instead of index order (differences at round-off level).
-    for (int kk = 1; 2 * kk <= n_act; ++kk) {
-      const int j = (g + kk) % n_act;
-      const double qx = __shfl(px, base + j, 64), qy = __shfl(py, base + j, 64);
-      const double wx = __shfl(vx, base + j, 64), wy = __shfl(vy, base + j, 64);
-      const double dfx = qx - px, dfy = qy - py;
-      const double z = dfx * dfx + dfy * dfy;
-      const double inv_nd = rsqrt_pos(fmax(z, 1e-300));
-      const double nd = z * inv_nd;
-      const double ex = z > 0 ? dfx * inv_nd : dfx, ey = z > 0 ? dfy * inv_nd : dfy;
-      const double ivx = kLam * (vx - wx) + ex, ivy = kLam * (vy - wy) + ey;
-      const double inv_il = rsqrt_pos(ivx * ivx + ivy * ivy);
-      const double il = (ivx * ivx + ivy * ivy) * inv_il;
-      const double ix = ivx * inv_il, iy = ivy * inv_il;
-      // equal velocities (two standing people): theta is mathematically 0 and the reference gets its libm's last-bit
-      // noise (its thetaSign is then 0 or +-1 by chance); take exactly 0, the convention of the hot path
-      const bool same_vel = (kLam * (vx - wx) == 0.0) && (kLam * (vy - wy) == 0.0);
-      // theta = wrap(atan2(e) - atan2(i)) is the angle from i to e = atan2(i x e, i . e): one table arctangent away from
-      // theta = 0 and |theta| = pi, the reference's own two-atan2 form next to them (its last bits decide thetaSign)
-      const double cross = ix * ey - iy * ex, dot = ix * ex + iy * ey;
-      double theta = atan2_dir(mt, cross, dot);
-      if (!(fabs(cross) >= 1e-6)) theta = proj_wrap(proj_wrap(atan2(ey, ex)) - proj_wrap(atan2(iy, ix)));
-      theta = same_vel ? 0.0 : theta;
-      const double Bq = kGam * il;
-      const double earg = -nd * inv_il * (1.0 / kGam);  // -|diff| / B
-      const double a1 = kNp * Bq * theta, a2 = kN * Bq * theta;
-      const double fv = -exp_tab(mt, fma(-a1, a1, earg));
-      const double sgn = (theta == 0) ? 0.0 : ((theta > 0) ? 1.0 : -1.0);  // sfm.hpp:265-270
-      const double fa = -sgn * exp_tab(mt, fma(-a2, a2, earg));
-      const double sfx = kFs * (fv * ix + fa * (-iy));
-      const double sfy = kFs * (fv * iy + fa * ix);
+    // Two rounds per trip: their evaluations are independent chains, so each lane keeps two in flight (the kernel runs
+    // with two wavefronts per SIMD and is bound by the latency of one chain otherwise).
+    for (int kk = 1; 2 * kk <= n_act; kk += 2) {
+      const bool two = 2 * (kk + 1) <= n_act;
       const bool act = g < n_act;
-      if (act) { fx += sfx; fy += sfy; }
+      double sfx[2], sfy[2];
+      ProjPair q[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k = (h == 1 && !two) ? kk : kk + h;
+        const int j = (g + k) % n_act;
+        const double qx = __shfl(px, base + j, 64), qy = __shfl(py, base + j, 64);
+        const double wx = __shfl(vx, base + j, 64), wy = __shfl(vy, base + j, 64);
+        proj_pair_begin(mt, qx - px, qy - py, vx - wx, vy - wy, q[h]);
+      }
+      q[0].near_axis = q[0].near_axis && act;  // idle lanes of the group carry no agent
+      q[1].near_axis = q[1].near_axis && act;
+      if (__builtin_expect(q[0].near_axis || q[1].near_axis, 0)) { proj_pair_exact_theta(q[0]); proj_pair_exact_theta(q[1]); }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) proj_pair_end(mt, q[h], sfx[h], sfy[h]);
+      if (act) { fx += sfx[0]; fy += sfy[0]; }
       if (2 * kk != n_act) {
         const int src = (g - kk + n_act) % n_act;
-        const double rx = __shfl(sfx, base + src, 64), ry = __shfl(sfy, base + src, 64);
+        const double rx = __shfl(sfx[0], base + src, 64), ry = __shfl(sfy[0], base + src, 64);
         if (act) { fx -= rx; fy -= ry; }
+      }
+      if (two) {
+        if (act) { fx += sfx[1]; fy += sfy[1]; }
+        if (2 * (kk + 1) != n_act) {
+          const int src = (g - kk - 1 + n_act) % n_act;
+          const double rx = __shfl(sfx[1], base + src, 64), ry = __shfl(sfy[1], base + src, 64);
+          if (act) { fx -= rx; fy -= ry; }
+        }
       }
     }
     // ---- updatePosition (sfm.hpp:525-551)
@@ -192,7 +233,11 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
       if (sp > des) { vx = (z > 0 ? vx * inv : vx) * des; vy = (z > 0 ? vy * inv : vy) * des; }
     }
     const double init_yaw = yaw;
-    yaw = proj_wrap(atan2(vy, vx));
+    {  // atan2(vy, vx) lies in [-pi, pi] already: the wrap only moves -pi (vy = -0, vx < 0) to... itself + 2 pi = pi
+      const double m = fmax(fabs(vx), fabs(vy));
+      const double a = (m > 1e-100 && m < 1e100) ? atan2_dir(mt, vy, vx) : atan2(vy, vx);
+      yaw = proj_wrap(a);
+    }
     av = proj_wrap(yaw - init_yaw) / dt;
     px += vx * dt; py += vy * dt;
     lv = proj_sqrt(vx * vx + vy * vy);

@@ -14,7 +14,8 @@ HOST = os.path.join(ROOT, "nav2_social_mpc_controller_amd", "host")
 
 def make_plans(seed, B, L=160):
     """Global plans: constant-curvature arcs with 0.05-0.1 m spacing; the robot starts near the first pose, sometimes
-    turned away from the plan (rotate-in-place branch), some plans end before max_steps steps (goal reached)."""
+    turned away from the plan (rotate-in-place branch), sometimes 1-3 m off it (no pose inside the look-ahead circle:
+    the closest-pose rule); some plans end before max_steps steps (goal reached)."""
     rng = np.random.default_rng(seed)
     plan = np.zeros((B, L, 2))
     plan_len = np.where(rng.uniform(size=B) < 0.25, rng.integers(3, 12, size=B), rng.integers(12, L + 1, size=B)).astype(np.int32)
@@ -22,7 +23,8 @@ def make_plans(seed, B, L=160):
     for s in range(B):
         x, y, th = rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi)
         k, ds = rng.uniform(-0.6, 0.6), rng.uniform(0.05, 0.1)
-        pose[s] = [x + rng.uniform(-0.2, 0.2), y + rng.uniform(-0.2, 0.2),
+        off = rng.uniform(1.0, 3.0) if s % 7 == 3 else 0.0
+        pose[s] = [x + rng.uniform(-0.2, 0.2) + off, y + rng.uniform(-0.2, 0.2) - off,
                    th + (rng.uniform(-0.5, 0.5) if s % 5 else rng.uniform(2.0, 4.0))]
         for i in range(plan_len[s]):
             plan[s, i] = [x, y]
@@ -91,16 +93,29 @@ def test_pyref_edge_cases(hostlib):
     assert tp.max_steps == 60 and params(time_step=0.05, max_time=1.5).max_steps == 30
 
 
+# (L, max_time): which kernel serves the call — plans in registers with 8 / 16 / 25 / 32 poses per lane in
+# four-wavefront blocks, one-wavefront blocks for long horizons (park of the step outputs in LDS), and the kernel that
+# searches the plan in memory (plans over 512 poses, horizons over 256 steps)
+TRAJ_SHAPES = [(100, 1.5), (160, 1.5), (390, 1.5), (500, 3.0), (600, 1.5), (160, 6.0), (120, 14.0)]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("omni", [False, True])
-def test_gpu_trajectorize_matches_pyref(omni):
+@pytest.mark.parametrize("L,max_time", TRAJ_SHAPES)
+def test_gpu_trajectorize_matches_pyref(omni, L, max_time):
     from nav2_social_mpc_controller_amd.params import OptimizerParams
     from nav2_social_mpc_controller_amd.solver import BatchSolver
-    tp = params(omni, desired_linear_vel=0.6, max_time=1.5)
-    B = 203
-    plan, plan_len, pose = make_plans(12, B)
+    tp = params(omni, desired_linear_vel=0.6, max_time=max_time)
+    B = 203 if max_time <= 3.0 else 67
+    plan, plan_len, pose = make_plans(12 + L, B, L)
     plan_len[7] = 1                        # SMPC_TRAJ_SHORT_PLAN
     plan[9, :plan_len[9]] += 1000.0        # SMPC_TRAJ_NO_WAYPOINT
+    # a pose exactly on the look-ahead circle (the reference's sqrt(z) <= lookahead decides): straight plan along x
+    # with 0.1 m spacing, robot at its first pose
+    plan_len[11] = min(L, 40)
+    plan[11, :plan_len[11], 0] = 0.1 * np.arange(plan_len[11]); plan[11, :plan_len[11], 1] = 0.0
+    pose[11] = [0.0, 0.0, 0.3]
+    assert abs(np.hypot(*plan[11, 4]) - tp.lookahead_dist) < 1e-15
     s = BatchSolver(OptimizerParams.readme())
     got = s.trajectorize(tp, plan, plan_len, pose)
     worst = 0.0

@@ -25,6 +25,13 @@ for _ in range(ticks):
     ep.tick()
 ep.synchronize()
 dt = (time.perf_counter() - t0) / ticks
+tm = {}
+acc = {}
+for _ in range(5):  # per-stage HIP-event times (each stage synchronised: not the pipelined tick time)
+    ep.tick(timing=tm)
+    for k, v in tm.items():
+        acc[k] = acc.get(k, 0.0) + v / 5
+print("stage ms:", {k: round(v, 4) for k, v in acc.items()})
 st = ep.res["status"].cpu().numpy()
 print(f"episode B={B} N={N}: {dt*1e3:.3f} ms/tick -> {B/dt:.0f} controller ticks/s; last-tick status {np.bincount(st, minlength=3)} "
       f"iters mean {ep.res['iterations'].double().mean().item():.1f} sweeps mean {ep.res['evaluations'].double().mean().item():.1f}; proj errors {(ep.proj_error != 0).sum().item()}")

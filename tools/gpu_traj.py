@@ -11,7 +11,7 @@ B = 8192
 rng = np.random.default_rng(0)
 pose = np.stack([rng.uniform(-5, 5, B), rng.uniform(-5, 5, B), rng.uniform(-3, 3, B)], 1)
 plan, plan_len = arc_plans(pose, rng.uniform(-0.24, 0.24, B), L=400)
-tp = TrajectorizerParams(desired_linear_vel=0.6, max_time=1.5)
+tp = TrajectorizerParams(desired_linear_vel=0.6, max_time=float(sys.argv[1]) if len(sys.argv) > 1 else 1.5)
 s = BatchSolver(OptimizerParams.readme())
 dev = "cuda:0"
 tb = s.trajectorize_c(tp, B, 400, 1)
@@ -27,4 +27,4 @@ ms = []
 for _ in range(6):
     s.trajectorize_device(tb, to)
     ms.append(s.last_kernel_ms())
-print("trajectorize B=8192 L=400: ms", [round(m, 3) for m in ms], "n_poses mean", o["n"].double().mean().item(), "errors", int((o["e"] != 0).sum()))
+print(f"trajectorize B=8192 L=400 max_steps={tp.max_steps}: ms", [round(m, 3) for m in ms], "n_poses mean", o["n"].double().mean().item(), "errors", int((o["e"] != 0).sum()))
