@@ -96,6 +96,22 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
     tick_s = (time.perf_counter() - t0) / ticks
     tm = {}
     ep.tick(timing=tm)
+    # the same robots as three independent shards (streams), each tick of a shard one HIP graph launch
+    from nav2_social_mpc_controller_amd.episode import ShardedEpisode
+    shards = 3
+    se = ShardedEpisode(prm, scenes, curv, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]),
+                        float(np.float32(0.1)), device=device_index, plan=plan, plan_len=plan_len, traj_params=tp,
+                        fov_angle=np.pi, shards=shards, graphs=True)
+    for _ in range(2):
+        se.tick()
+    se.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        se.tick()
+    se.synchronize()
+    shard_tick_s = (time.perf_counter() - t0) / ticks
+    shard_failures = int((se.gather("status") == 2).sum().item())
+    del se
     S1 = tp.max_steps + 1
     alg = {  # algorithmic bytes per scene: every input read once, every output written once
         "trajectorize": 8 * (2 * L + 3) + 4 + 8 * S1 * (3 + 2 + 1) + 8,
@@ -110,6 +126,10 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
         stages[k] = {"kernel_ms": ms, "algorithmic_GBps": B * alg[k] / (ms * 1e-3) / 1e9, "bytes_per_scene": alg[k]}
     stages["solve"] = {"kernel_ms": tm["solve_ms"]}
     return {"ticks_per_s": B / tick_s, "ms_per_tick": tick_s * 1e3, "ticks_timed": ticks,
+            "sharded": {"shards": shards, "hip_graphs": True, "ms_per_tick": shard_tick_s * 1e3, "ticks_per_s": B / shard_tick_s,
+                        "last_tick_failures": shard_failures,
+                        "note": "the same robots as independent shards on separate streams (ShardedEpisode): one graph launch "
+                                "per shard and tick, solve grids sized by smpc_set_solve_share, chain kernels at wave priority 3"},
             "chain": "trajectorize(f3) -> fov filter + people_to_status(f4, f2) -> format_to_optimize(f2) -> project_people(f1) "
                      "-> solve(a1-a12, people block staged inside) -> memory store(f2)",
             "stages": stages, "last_tick_failures": int((ep.res["status"] == 2).sum().item()),

@@ -76,6 +76,7 @@ class SmpcSceneBatch(C.Structure):
         ("resolution", C.c_double),
         ("people_records", C.c_void_p),
         ("people_aux", C.c_void_p),
+        ("order", C.c_void_p),
     ]
 
 
@@ -208,6 +209,7 @@ EXPORTED_SYMBOLS = [
     "smpc_create",
     "smpc_destroy",
     "smpc_set_stream",
+    "smpc_set_solve_share",
     "smpc_solve_batch",
     "smpc_eval_batch",
     "smpc_project_people_batch",

@@ -54,6 +54,7 @@ struct KParams {
   // staged people block (smpc_stage_people_batch / the library's own staging pass): what the sweep reads
   const double* people_rec;  // [B][N][T][4]  px, py, vx, vy of people_proj[t + 1][a]
   const double* people_aux;  // [B][T][2]     bit mask of valid agents (u64 bits), agent-angle target (kNoTarget: none)
+  const int32_t* order;      // [B] queue order of the solve kernel (null: index order)
   double* stage_rec;         // staging kernel outputs (same layouts)
   double* stage_aux;
   unsigned long long* stamps;  // diagnostic builds only (SMPC_STAMPS): per-wave cycle sums per phase, [grid][8]

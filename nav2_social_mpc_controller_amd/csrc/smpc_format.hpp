@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "smpc_math.hpp"
+
 namespace smpc {
 
 struct FormatParams {
@@ -33,6 +35,7 @@ __device__ inline double format_yaw_roundtrip(double yaw) {
 
 // grid: ceil(B * (T + 1) / 256) blocks of 256 lanes; lane = (scene, pose index i)
 __global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) {
+  SMPC_CHAIN_PRIORITY();
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int Tp = p.T + 1;
   if (gid >= (long long)p.B * Tp) return;
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) 
 // Second pass of the format step: mark freshly filled memory records valid (after every lane of the first kernel has
 // read the flag).
 __global__ __launch_bounds__(256) void smpc_format_mark_kernel(int B, int32_t* valid) {
+  SMPC_CHAIN_PRIORITY();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < B) valid[s] = 1;
 }
@@ -110,6 +114,7 @@ __device__ inline double people_shortest_angular_distance(double from, double to
 // Optimizer::people_to_status (src/optimizer.cpp:454-482): one lane per scene, the persons of a scene are walked in
 // order (the filter compacts, people_to_status truncates to the first N and pads with t = -1).
 __global__ __launch_bounds__(256) void smpc_people_to_status_kernel(const PeopleParams p) {
+  SMPC_CHAIN_PRIORITY();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= p.B) return;
   const int cnt = min(max(p.count[s], 0), p.Np);
@@ -160,6 +165,7 @@ struct StoreParams {
 };
 
 __global__ __launch_bounds__(256) void smpc_memory_store_kernel(const StoreParams p) {
+  SMPC_CHAIN_PRIORITY();
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int Tp = p.T + 1;
   if (gid >= (long long)p.B * Tp) return;
@@ -183,6 +189,7 @@ struct SelectParams {
 
 // computeVelocityCommands' choice of the returned command (src/social_mpc_controller.cpp:180-189, 241-245, 250-256).
 __global__ __launch_bounds__(256) void smpc_select_command_kernel(const SelectParams p) {
+  SMPC_CHAIN_PRIORITY();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= p.B) return;
   const int n = p.traj_n ? p.traj_n[s] : p.T + 1;

@@ -109,6 +109,7 @@ struct smpc_handle {
   hipEvent_t ev0, ev1;
   bool timed;
   int* queue;  // device-side scene queue head
+  int share;   // smpc_set_solve_share: concurrent solve launches the persistent grid leaves room for
   double* stage_rec;  // staged people block of the latest call that did not bring its own (grow-only)
   double* stage_aux;
   size_t stage_rec_bytes, stage_aux_bytes;
@@ -281,6 +282,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     // persistent sweep engine: no more waves than can be resident; scenes come from the queue
     int per_cu = 0;
     SMPC_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), smpc::kWave, shmem));
+    if (h->share > 1) per_cu /= h->share;  // room for the other launches of smpc_set_solve_share
     if (per_cu < 1) per_cu = 1;
     if (const char* cap = std::getenv("SMPC_MAX_WAVES_PER_CU")) {  // experiment knob: limit resident waves per CU
       const int c = std::atoi(cap);
@@ -409,6 +411,7 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
   h->stream = nullptr;
   h->timed = false;
   h->queue = nullptr;
+  h->share = 1;
   h->stage_rec = nullptr;
   h->stage_aux = nullptr;
   h->stage_rec_bytes = h->stage_aux_bytes = 0;
@@ -448,6 +451,12 @@ double smpc_last_kernel_ms(smpc_handle* h) {
   return (double)ms;
 }
 
+int smpc_set_solve_share(smpc_handle* h, int32_t n) {
+  if (!h || n < 1) { set_error("null handle or share < 1"); return SMPC_ERR_INVALID_ARG; }
+  h->share = n;
+  return SMPC_OK;
+}
+
 int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_batch* out) {
   Dims d;
   SMPC_TRY(validate(h, sb, &d));
@@ -459,6 +468,19 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   SMPC_TRY(bind_inputs(h, sb, d, &k, &st));
   SMPC_TRY(bind_people(h, sb, k, &st));
   const size_t B = sb->B, T = sb->T;
+  if (sb->order) {  // queue order hint
+    if (sb->on_device) {
+      k.order = sb->order;
+    } else {
+      std::vector<uint8_t> seen(B, 0);
+      for (size_t i = 0; i < B; ++i) {
+        const int32_t v = sb->order[i];
+        if (v < 0 || (size_t)v >= B || seen[v]) { set_error("order is not a permutation of 0..B-1"); return SMPC_ERR_INVALID_ARG; }
+        seen[v] = 1;
+      }
+      SMPC_TRY(st.up(sb->order, B, &k.order, h->stream));
+    }
+  }
   if (sb->on_device) {
     k.o_params = out->params; k.o_cmds = out->cmds; k.o_path = out->path; k.o_status = out->status; k.o_reason = out->reason;
     k.o_iterations = out->iterations; k.o_evaluations = out->evaluations; k.o_initial_cost = out->initial_cost; k.o_final_cost = out->final_cost;

@@ -548,7 +548,16 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     // ---------------------------------------------------------------- fetch the next scene for idle slots
     if (R.phase == PH_FETCH) {
       int scene = 0;
-      if (c.sl == 0) scene = atomicAdd(k.queue, 1);
+      if (c.sl == 0) {
+        scene = atomicAdd(k.queue, 1);
+        if (k.order) {  // the caller's order (longest scenes first); an entry outside the batch is skipped
+          while (scene < k.B) {
+            const int want = k.order[scene];
+            if (want >= 0 && want < k.B) { scene = want; break; }
+            scene = atomicAdd(k.queue, 1);
+          }
+        }
+      }
       scene = __shfl(scene, slot * W, 64);
       if (scene < k.B) {
         load_scene<W>(c, scene);
@@ -935,6 +944,7 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
 // One slot per scene like the sweep kernels; once per people block (a solve re-reads the records ~50 times).
 template <int W>
 __global__ __launch_bounds__(64) void smpc_stage_kernel(const KParams) {
+  SMPC_CHAIN_PRIORITY();
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int S = kWave / W;
   extern __shared__ __attribute__((aligned(32))) double lds_all[];

@@ -25,6 +25,16 @@
 #define SMPC_TAB_AS
 #endif
 
+// The kernels of the per-tick chain around the solve (trajectorize, people filter, formatting, projection, staging,
+// memory store, command selection) are short dependent chains: alone they leave the SIMDs mostly idle, next to the
+// persistent solve kernel of another stream they would wait behind its wavefronts for every issue slot (measured: 5-10x
+// longer). They run at the highest user wave priority instead; the solve kernel stays at 0.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMPC_CHAIN_PRIORITY() __builtin_amdgcn_s_setprio(3)
+#else
+#define SMPC_CHAIN_PRIORITY() ((void)0)
+#endif
+
 namespace smpc {
 
 struct MathTab {

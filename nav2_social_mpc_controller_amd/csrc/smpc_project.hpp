@@ -103,6 +103,7 @@ __device__ inline void proj_pair_end(MathTabP mt, const ProjPair& q, double& sfx
 }
 
 __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
+  SMPC_CHAIN_PRIORITY();
   const auto& p = *(const ProjParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const MathTabP mt = &p.mt;
   const int lane = threadIdx.x & 63;

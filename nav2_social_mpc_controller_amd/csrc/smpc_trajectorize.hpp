@@ -53,6 +53,7 @@ __device__ inline double traj_yaw_roundtrip(double yaw) {  // setRPY(0, 0, yaw) 
 // latency they save.
 __global__ __launch_bounds__(64) void smpc_trajectorize_long_kernel(const TrajParams p) {
 #pragma clang fp contract(off)  // distances decide the way-point: keep them the plain IEEE products and sums of the reference
+  SMPC_CHAIN_PRIORITY();
   const int lane = threadIdx.x & 63;
   const int grp = lane / kTrajGroup, gl = lane - grp * kTrajGroup;
   const int scene = blockIdx.x * (64 / kTrajGroup) + grp;
@@ -265,6 +266,7 @@ __device__ __noinline__ int traj_closest(const double* plan, int Lp, double rx, 
 template <int kR>
 __global__ __launch_bounds__(kTrajBlock) void smpc_trajectorize_kernel(const TrajParams) {
 #pragma clang fp contract(off)  // distances decide the way-point: keep them the plain IEEE products and sums of the reference
+  SMPC_CHAIN_PRIORITY();
   extern __shared__ double traj_park[];  // [4 groups][max_steps][kTrajParkDoubles]
   const auto& p = *(const TrajParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const MathTabP mt = &p.mt;

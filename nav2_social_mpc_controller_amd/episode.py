@@ -57,11 +57,14 @@ class TickRecord:
 class BatchEpisode:
     def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
                  od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
-                 plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None):
+                 plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None,
+                 order_hint: bool = False):
         """scenes: the start state (pose0, people at step 0, costmaps); w_ref [B]: curvature of the arc stand-in;
         od_*: one ObstacleDistance grid shared by all scenes. plan [B,L,2] + plan_len [B] + traj_params: global plans,
         trajectorized on the device every tick (the plan must stay longer than the horizon for the whole episode).
-        fov_angle: field-of-view half angle of the people filter (reference default pi/4); None = no filter."""
+        fov_angle: field-of-view half angle of the people filter (reference default pi/4); None = no filter.
+        order_hint: hand the solve kernel's queue the scenes sorted by the previous tick's sweep counts, longest first
+        (smpc_scene_batch.order; the results are the same, the lone launch is shorter)."""
         import torch
 
         self.torch = torch
@@ -126,6 +129,11 @@ class BatchEpisode:
         self.rb, self.res = self.solver.alloc_results(B, T, self.dev)
         self.cmd_vel = torch.zeros((B, 2), **f64)                      # the command returned to the robot this tick
         self.cmd_source = torch.zeros(B, dtype=torch.int32, device=self.dev)  # 0 optimised, 1 trajectorizer, 2 creep
+        self.order_hint = order_hint
+        self.graph = None
+        self.gstream = None
+        # queue order for the next solve (from the last solve's sweep counts; index order before the first one)
+        self.order = torch.arange(B, dtype=torch.int32, device=self.dev)
         self.ticks = 0
         self.parked = None  # plan mode: scenes parked in the last tick (bool tensor)
 
@@ -164,8 +172,6 @@ class BatchEpisode:
         that receives the HIP-event duration (ms) of each stage's kernel (synchronises after every stage)."""
         torch = self.torch
         s, prm, B, T, N = self.solver, self.params, self.B, self.T, self.N
-        if not self.pose.is_contiguous():
-            self.pose = self.pose.contiguous()
         pose_before = self.pose.cpu().numpy().copy() if record else None
         self._plan()
         if timing is not None and self.plan is not None:
@@ -224,9 +230,13 @@ class BatchEpisode:
         sb.costmap, sb.costmap_shared = self.costmap.data_ptr(), 1 if self.costmap_shared else 0
         sb.size_x, sb.size_y = self.size_x, self.size_y
         sb.costmap_origin, sb.resolution = self.costmap_origin.data_ptr(), self.resolution
+        if self.order_hint:
+            sb.order = self.order.data_ptr()  # longest scenes of the previous period first
         s.solve_device(sb, self.rb)
         if timing is not None:
             timing["solve_ms"] = s.last_kernel_ms()
+        if self.order_hint:
+            self.order.copy_(BatchSolver.longest_first(self.res["evaluations"]))
         # scenes whose trajectorized path is shorter than the horizon (the robot is about to reach the end of its plan)
         # would need a smaller T than the batch has: they are parked — treated like an unusable solve from here on
         if self.plan is not None:
@@ -254,15 +264,105 @@ class BatchEpisode:
         v, w, th = self.cmd_vel[:, 0], self.cmd_vel[:, 1], self.pose[:, 2]
         moved = torch.stack([self.pose[:, 0] + v * torch.cos(th) * dt, self.pose[:, 1] + v * torch.sin(th) * dt, th + w * dt], dim=1)
         optimised = (self.cmd_source == 0)[:, None]
-        self.pose = torch.where(optimised, self.res["path"][:, 0, :], moved).contiguous()
-        self.speed = self.cmd_vel.clone()
+        # state is updated in place: every buffer the kernels read keeps its address from tick to tick (capture_graph)
+        self.pose.copy_(torch.where(optimised, self.res["path"][:, 0, :], moved))
+        self.speed.copy_(self.cmd_vel)
         self.persons[:, :, 0] += self.persons[:, :, 2] * dt
         self.persons[:, :, 1] += self.persons[:, :, 3] * dt
         self.ticks += 1
         return TickRecord(**rec) if record else None
 
+    def capture_graph(self, stream=None):
+        """Record one tick (every kernel of the chain and the torch ops of the world model) into a HIP graph on `stream`
+        (a new side stream by default) and make tick() replay it: one graph launch per control period instead of ~25
+        kernel launches from Python, which is what lets several independent shards keep the GPU busy (ShardedEpisode).
+        One warm-up tick runs first (the library's buffers grow on first use); the episode's state is put back after it."""
+        torch = self.torch
+        self.gstream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
+        self.gstream.wait_stream(torch.cuda.current_stream(self.dev))
+        self.solver.set_stream(self.gstream.cuda_stream)
+        state = ("pose", "speed", "persons", "mem_path", "mem_cmds", "mem_valid", "order")
+        with torch.cuda.stream(self.gstream):
+            saved = {k: getattr(self, k).clone() for k in state}
+            ticks = self.ticks
+            self.tick()  # warm-up on the capture stream: the library's buffers grow, torch's allocator settles
+        self.gstream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.gstream):
+            self.tick()
+        with torch.cuda.stream(self.gstream):  # the world is where it was before the warm-up tick
+            for k in state:
+                getattr(self, k).copy_(saved[k])
+        self.ticks = ticks
+        return self.graph
+
+    def replay(self):
+        """One control period through the captured graph (on the capture stream)."""
+        with self.torch.cuda.stream(self.gstream):
+            self.graph.replay()
+        self.ticks += 1
+
     def synchronize(self):
         self.torch.cuda.synchronize()
+
+
+class ShardedEpisode:
+    """The robots of a batch are independent of each other (every scene has its own plan, people, memory), so a tick of
+    B robots can be issued as `shards` chains of B / shards robots on separate HIP streams: while one shard's solve
+    launch drains its last long-running scenes, the other shards' kernels keep the CUs busy (the same overlap the
+    serving bench gets from independent batches; a single chain pays the tail of every launch). Three things make it
+    pay (measured at 8192 robots, 8 people, tools/gpu_episode.py / tools/shard_caps.sh): every shard's tick is one HIP
+    graph launch (from Python the ~25 launches per shard-tick make the host the bottleneck); every solve launch sizes its
+    persistent grid to 1 / shards of the resident wavefronts (smpc_set_solve_share: oversubscribed grids leave the other
+    shards' small kernels waiting for wave slots); the small kernels run at the highest wave priority (next to another
+    shard's solve they took 5-10x longer at equal priority). Three shards: 2.72 ms per tick against 3.24-3.32 ms for
+    the single chain; two: 2.87; four and more fall behind again (more streams than hardware queues). Per-robot results
+    are those of the one-stream episode bit for bit (kernels take every decision per scene / per lane)."""
+
+    def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
+                 od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
+                 plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None,
+                 shards: int = 3, order_hint: bool = False, graphs: bool = True):
+        import torch
+
+        self.torch = torch
+        B = scenes.B
+        shards = max(1, min(shards, B))
+        edges = [B * k // shards for k in range(shards + 1)]
+        self.slices = [slice(edges[k], edges[k + 1]) for k in range(shards) if edges[k + 1] > edges[k]]
+        self.streams = [torch.cuda.Stream(device=f"cuda:{device}") for _ in self.slices]
+        self.parts = []
+        for sl, st in zip(self.slices, self.streams):
+            idx = np.arange(sl.start, sl.stop)
+            with torch.cuda.stream(st):  # the shard's solver handle binds to the stream current at construction
+                self.parts.append(BatchEpisode(
+                    params, scenes.select(idx), np.asarray(w_ref)[idx], od_indexes, od_origin, od_resolution, device=device,
+                    plan=None if plan is None else plan[idx], plan_len=None if plan_len is None else plan_len[idx],
+                    traj_params=traj_params, fov_angle=fov_angle, order_hint=order_hint))
+        self.B = B
+        self.graphs = graphs
+        for part in self.parts:  # every shard's persistent solve grid takes its share of the resident wavefronts
+            part.solver.set_solve_share(len(self.parts))
+        if graphs:  # one HIP graph per shard: a tick is `shards` graph launches
+            for part, st in zip(self.parts, self.streams):
+                part.capture_graph(st)
+
+    def tick(self):
+        for part, st in zip(self.parts, self.streams):
+            if self.graphs:
+                part.replay()
+            else:
+                with self.torch.cuda.stream(st):
+                    part.tick()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+    def gather(self, name: str):
+        """Concatenated per-robot tensor: a key of BatchEpisode.res ("status", "cmds", ...) or an attribute ("pose",
+        "cmd_vel", "cmd_source", "proj_error")."""
+        self.synchronize()
+        return self.torch.cat([p.res[name] if name in p.res else getattr(p, name) for p in self.parts], dim=0)
 
 
 def far_obstacle_grid(cells: int = 120, resolution: float = 0.1, origin=(-6.0, -6.0)):

@@ -54,6 +54,8 @@ def load_library():
     lib.smpc_destroy.restype = None
     lib.smpc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.smpc_set_stream.restype = C.c_int
+    lib.smpc_set_solve_share.argtypes = [C.c_void_p, C.c_int32]
+    lib.smpc_set_solve_share.restype = C.c_int
     lib.smpc_solve_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.POINTER(SmpcResultBatch)]
     lib.smpc_solve_batch.restype = C.c_int
     lib.smpc_eval_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.POINTER(SmpcEvalOut)]
@@ -116,6 +118,10 @@ class BatchSolver:
     def set_stream(self, stream_ptr: int):
         _check(self.lib, self.lib.smpc_set_stream(self._h, C.c_void_p(stream_ptr)), "smpc_set_stream")
 
+    def set_solve_share(self, n: int):
+        """smpc_set_solve_share: this handle's solve launches leave room for n - 1 concurrent ones (other streams)."""
+        _check(self.lib, self.lib.smpc_set_solve_share(self._h, int(n)), "smpc_set_solve_share")
+
     def math_probe(self, fn: int, a: np.ndarray, b: np.ndarray = None):
         """smpc_math_probe: the sweep's elementary functions evaluated on the device (see include/smpc.h)."""
         a = np.ascontiguousarray(a, dtype=np.float64)
@@ -135,7 +141,10 @@ class BatchSolver:
         return float(self.lib.smpc_last_kernel_ms(self._h))
 
     # -- host-memory path (stages through HBM inside the library) ---------------------------------
-    def solve(self, scenes: SceneBatch):
+    def solve(self, scenes: SceneBatch, order: np.ndarray = None):
+        """Solve B scenes (host arrays in, host arrays out). order: optional queue order of the persistent kernel, a
+        permutation of 0..B-1 (smpc_scene_batch.order: longest scenes first shortens a lone launch; results do not
+        depend on it)."""
         CH, bl, nb, P, M, _ = self.params.dims(scenes.T, True)
         scenes.validate(P)
         B, T = scenes.B, scenes.T
@@ -148,8 +157,20 @@ class BatchSolver:
         for k, v in out.items():
             setattr(rb, k, v.ctypes.data)
         sb = scenes.to_c()
+        if order is not None:
+            order = np.ascontiguousarray(order, np.int32)
+            assert order.shape == (B,)
+            sb.order = order.ctypes.data
         _check(self.lib, self.lib.smpc_solve_batch(self._h, C.byref(sb), C.byref(rb)), "smpc_solve_batch")
         return out
+
+    @staticmethod
+    def longest_first(evaluations):
+        """Queue order for the next solve of the same (or the next control period's) scenes from the sweep counts of the
+        last one: a torch int32 tensor on the device of `evaluations`, scenes with the most sweeps first."""
+        import torch
+
+        return torch.argsort(evaluations, descending=True, stable=True).to(torch.int32)
 
     def row_permutation(self, T: int, has_people: bool = True):
         """perm with reference_rows = critic_major_rows[perm] (smpc_eval_batch_out.row_order 1 -> 0) for one scene."""

@@ -151,3 +151,32 @@ def test_short_plans_fall_back_to_the_trajectorizer_command():
     assert (r.traj_n_poses[short] < sc.T + 1).all() and (r.traj_n_poses[~short] == tp.max_steps + 1).all()
     assert (src[short] == 1).all() and (src[~short] == 0).all()
     assert np.array_equal(ep.cmd_vel.cpu().numpy()[short], r.plan_cmds[short, 0])
+
+
+@pytest.mark.gpu
+def test_sharded_episode_equals_the_single_chain():
+    """The robots of a batch do not interact: four shards on four HIP streams must return, robot by robot, the very
+    numbers of the one-stream episode (three ticks, people + global plans + field-of-view filter)."""
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode, ShardedEpisode, arc_plans
+    from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
+    from nav2_social_mpc_controller_amd.scenes import make_scenes, uniform
+
+    prm = OptimizerParams.readme()
+    tp = TrajectorizerParams(desired_linear_vel=0.6, lookahead_dist=0.4, max_angular_vel=1.0, time_step=0.05, max_time=1.5)
+    B, N = 203, 8   # not a multiple of the shard count
+    sc = make_scenes(prm, B, N)
+    w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
+    plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)
+    od = (np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)))
+    kw = dict(plan=plan, plan_len=plan_len, traj_params=tp, fov_angle=2.0)
+    one = BatchEpisode(prm, sc, w_ref, *od, **kw)
+    four = ShardedEpisode(prm, sc, w_ref, *od, shards=4, graphs=True, **kw)  # every shard's tick replayed from a HIP graph
+    assert [p.B for p in four.parts] == [50, 51, 51, 51]
+    for _ in range(3):
+        one.tick()
+        four.tick()
+    one.synchronize()
+    for name in ("status", "iterations", "cmds", "path", "final_cost"):
+        assert np.array_equal(one.res[name].cpu().numpy(), four.gather(name).cpu().numpy()), name
+    for name in ("pose", "cmd_vel", "cmd_source", "proj_error"):
+        assert np.array_equal(getattr(one, name).cpu().numpy(), four.gather(name).cpu().numpy()), name

@@ -1,0 +1,65 @@
+"""smpc_scene_batch.order: the queue order of the persistent solve kernel is a scheduling hint — every scene is solved
+by its own lanes from its own inputs, so the results must not depend on it, bit for bit."""
+import numpy as np
+import pytest
+
+from nav2_social_mpc_controller_amd.params import OptimizerParams
+from nav2_social_mpc_controller_amd.scenes import make_scenes
+
+
+@pytest.mark.gpu
+def test_results_do_not_depend_on_the_queue_order():
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+
+    prm = OptimizerParams.readme()
+    B = 777
+    sc = make_scenes(prm, B, 8)
+    s = BatchSolver(prm)
+    base = s.solve(sc)
+    rng = np.random.default_rng(5)
+    for order in (np.argsort(-base["evaluations"], kind="stable"), rng.permutation(B), np.arange(B)[::-1]):
+        got = s.solve(sc, order=order)
+        for k in base:
+            assert np.array_equal(base[k], got[k]), k
+
+
+@pytest.mark.gpu
+def test_a_host_order_that_is_not_a_permutation_is_refused():
+    from nav2_social_mpc_controller_amd.solver import BatchSolver, SmpcError
+
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 16, 3)
+    s = BatchSolver(prm)
+    for bad in (np.zeros(16, np.int32), np.arange(16)[::-1] + 1, np.r_[np.arange(15), -1]):
+        with pytest.raises(SmpcError, match="permutation"):
+            s.solve(sc, order=bad)
+
+
+@pytest.mark.gpu
+def test_device_order_entries_outside_the_batch_are_skipped():
+    """Device arrays are trusted, but a wrong entry must not become an out-of-bounds scene index: it is skipped (that
+    scene keeps whatever its output arrays held)."""
+    import torch
+
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+
+    prm = OptimizerParams.readme()
+    B = 64
+    sc = make_scenes(prm, B, 3)
+    s = BatchSolver(prm)
+    base = s.solve(sc)
+    sb, tens = sc.to_device()
+    rb, rt = s.alloc_results(B, sc.T)
+    rt["status"].fill_(-7)
+    order = torch.arange(B, dtype=torch.int32, device="cuda:0").flip(0).contiguous()
+    order[3] = B + 1000     # scene B-4 is never handed out
+    order[10] = -5          # scene B-11 neither
+    sb.order = order.data_ptr()
+    s.solve_device(sb, rb)
+    torch.cuda.synchronize()
+    st = rt["status"].cpu().numpy()
+    skipped = np.zeros(B, bool)
+    skipped[[B - 4, B - 11]] = True
+    assert (st[skipped] == -7).all()
+    assert np.array_equal(st[~skipped], base["status"][~skipped])
+    assert np.array_equal(rt["cmds"].cpu().numpy()[~skipped], base["cmds"][~skipped])

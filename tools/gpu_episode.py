@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from nav2_social_mpc_controller_amd.episode import BatchEpisode, arc_plans
+from nav2_social_mpc_controller_amd.episode import BatchEpisode, ShardedEpisode, arc_plans
 from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
 from nav2_social_mpc_controller_amd.scenes import make_scenes, uniform
 
@@ -25,6 +25,22 @@ for _ in range(ticks):
     ep.tick()
 ep.synchronize()
 dt = (time.perf_counter() - t0) / ticks
+only = [int(a) for a in sys.argv[5:]]
+for shards in (only or (-2, -3, -4)):  # the same robots as independent chains on separate streams
+    se = ShardedEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1, shards=abs(shards), graphs=shards < 0, **kw)
+    for _ in range(2):
+        se.tick()
+    se.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        se.tick()
+    se.synchronize()
+    ds = (time.perf_counter() - t0) / ticks
+    tag = " (HIP graphs)" if shards < 0 else ""
+    print(f"  {abs(shards)} shards{tag}: {ds*1e3:.3f} ms/tick -> {B/ds:.0f} controller ticks/s")
+    del se
+if only:
+    sys.exit(0)
 tm = {}
 acc = {}
 for _ in range(5):  # per-stage HIP-event times (each stage synchronised: not the pipelined tick time)
