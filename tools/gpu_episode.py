@@ -1,4 +1,6 @@
-"""Development probe: closed-loop batch episode throughput (format + project + solve + store per tick)."""
+"""Development probe: closed-loop batch episode throughput (format + project + solve + store per tick).
+usage: gpu_episode.py [B] [N] [ticks] [plan] [shard counts...]: a negative shard count replays HIP graphs, `0` skips the
+sharded runs (single chain + stage times only), no count runs -2 -3 -4 and then the single chain."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -26,7 +28,7 @@ for _ in range(ticks):
 ep.synchronize()
 dt = (time.perf_counter() - t0) / ticks
 only = [int(a) for a in sys.argv[5:]]
-for shards in (only or (-2, -3, -4)):  # the same robots as independent chains on separate streams
+for shards in ([] if only == [0] else (only or (-2, -3, -4))):  # the same robots as independent chains on separate streams
     se = ShardedEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1, shards=abs(shards), graphs=shards < 0, **kw)
     for _ in range(2):
         se.tick()
@@ -39,7 +41,7 @@ for shards in (only or (-2, -3, -4)):  # the same robots as independent chains o
     tag = " (HIP graphs)" if shards < 0 else ""
     print(f"  {abs(shards)} shards{tag}: {ds*1e3:.3f} ms/tick -> {B/ds:.0f} controller ticks/s")
     del se
-if only:
+if only and only != [0]:
     sys.exit(0)
 tm = {}
 acc = {}
