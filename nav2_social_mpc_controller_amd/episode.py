@@ -171,6 +171,9 @@ class BatchEpisode:
         """One controller period for all B robots. Returns a TickRecord when `record`, else None. `timing`: a dict
         that receives the HIP-event duration (ms) of each stage's kernel (synchronises after every stage)."""
         torch = self.torch
+        if self.gstream is not None and torch.cuda.current_stream(self.dev) != self.gstream:
+            with torch.cuda.stream(self.gstream):  # after capture_graph the library's handle lives on the capture stream
+                return self.tick(record, timing)
         s, prm, B, T, N = self.solver, self.params, self.B, self.T, self.N
         pose_before = self.pose.cpu().numpy().copy() if record else None
         self._plan()
@@ -322,7 +325,7 @@ class ShardedEpisode:
     def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
                  od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
                  plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None,
-                 shards: int = 3, order_hint: bool = False, graphs: bool = True):
+                 shards: int = 3, order_hint: bool = False, graphs: bool = True, solve_share: int = None):
         import torch
 
         self.torch = torch
@@ -342,7 +345,7 @@ class ShardedEpisode:
         self.B = B
         self.graphs = graphs
         for part in self.parts:  # every shard's persistent solve grid takes its share of the resident wavefronts
-            part.solver.set_solve_share(len(self.parts))
+            part.solver.set_solve_share(solve_share if solve_share else len(self.parts))
         if graphs:  # one HIP graph per shard: a tick is `shards` graph launches
             for part, st in zip(self.parts, self.streams):
                 part.capture_graph(st)

@@ -180,3 +180,9 @@ def test_sharded_episode_equals_the_single_chain():
         assert np.array_equal(one.res[name].cpu().numpy(), four.gather(name).cpu().numpy()), name
     for name in ("pose", "cmd_vel", "cmd_source", "proj_error"):
         assert np.array_equal(getattr(one, name).cpu().numpy(), four.gather(name).cpu().numpy()), name
+    # a shard can still be ticked outside its graph (recording / per-stage timing): same numbers again
+    one.tick()
+    r = four.parts[1].tick(record=True)
+    one.synchronize()
+    sl = four.slices[1]
+    assert np.array_equal(r.result["cmds"], one.res["cmds"].cpu().numpy()[sl])

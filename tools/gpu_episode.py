@@ -1,7 +1,7 @@
 """Development probe: closed-loop batch episode throughput (format + project + solve + store per tick).
 usage: gpu_episode.py [B] [N] [ticks] [plan] [shard counts...]: a negative shard count replays HIP graphs, `0` skips the
 sharded runs (single chain + stage times only), no count runs -2 -3 -4 and then the single chain."""
-import sys, time
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from nav2_social_mpc_controller_amd.episode import BatchEpisode, ShardedEpisode, arc_plans
@@ -29,7 +29,8 @@ ep.synchronize()
 dt = (time.perf_counter() - t0) / ticks
 only = [int(a) for a in sys.argv[5:]]
 for shards in ([] if only == [0] else (only or (-2, -3, -4))):  # the same robots as independent chains on separate streams
-    se = ShardedEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1, shards=abs(shards), graphs=shards < 0, **kw)
+    se = ShardedEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1, shards=abs(shards), graphs=shards < 0,
+                        solve_share=int(os.environ["SMPC_SHARE"]) if "SMPC_SHARE" in os.environ else None, **kw)
     for _ in range(2):
         se.tick()
     se.synchronize()
