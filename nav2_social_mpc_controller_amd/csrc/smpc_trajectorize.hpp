@@ -306,12 +306,12 @@ __global__ __launch_bounds__(kTrajBlock) void smpc_trajectorize_kernel(const Tra
     // wavefront holds a reachable pose there: the search of a step only visits those slots (2-3 of 25 for a 20 m plan).
     uint32_t near_slots = 0;
     {
-      const double reach = (look + fabs(p.desired_linear_vel) * p.time_step * p.max_steps) * (1.0 + 1e-6) + 1e-9;
+      const double reach = (fabs(look) + fabs(p.desired_linear_vel * p.time_step) * p.max_steps) * (1.0 + 1e-6) + 1e-9;
       const double reach2 = reach * reach;
 #pragma unroll
       for (int u = 0; u < kR; ++u) {
         const double z0 = (rx - px[u]) * (rx - px[u]) + (ry - py[u]) * (ry - py[u]);
-        near_slots |= __ballot(z0 <= reach2) ? (1u << u) : 0u;
+        near_slots |= __ballot(!(z0 > reach2)) ? (1u << u) : 0u;  // (a NaN bound or pose keeps the slot in the search)
       }
       asm volatile("" : "+s"(near_slots));  // one mask in one SGPR (not kR booleans in SGPR pairs): s_bitcmp1 per slot
     }
