@@ -294,7 +294,9 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     // a third wave per SIMD lengthens every trip more than it shortens the queue, and the tail of long scenes grows);
     // the third wave's registers and LDS then stay free for the launches of other streams, which is where the extra
     // occupancy pays. Only a batch with many scenes per slot takes every resident wave for itself.
-    const int two_per_simd = 8 * h->num_cu < resident ? 8 * h->num_cu : resident;
+    int lone_per_cu = 8;
+    if (const char* v = std::getenv("SMPC_LONE_WAVES_PER_CU")) { const int c = std::atoi(v); if (c >= 1) lone_per_cu = c; }  // experiment knob
+    const int two_per_simd = lone_per_cu * h->num_cu < resident ? lone_per_cu * h->num_cu : resident;
     if (grid > two_per_simd) grid = (grid >= 4 * resident) ? resident : two_per_simd;
     k.queue = h->queue;
     SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));

@@ -63,3 +63,21 @@ def test_device_order_entries_outside_the_batch_are_skipped():
     assert (st[skipped] == -7).all()
     assert np.array_equal(st[~skipped], base["status"][~skipped])
     assert np.array_equal(rt["cmds"].cpu().numpy()[~skipped], base["cmds"][~skipped])
+
+
+@pytest.mark.gpu
+def test_solve_share_changes_the_grid_not_the_results():
+    """smpc_set_solve_share sizes the persistent grid for n concurrent launches: same results, n < 1 refused."""
+    from nav2_social_mpc_controller_amd.solver import BatchSolver, SmpcError
+
+    prm = OptimizerParams.readme()
+    sc = make_scenes(prm, 8192 + 37, 8)   # more scene groups than the shared grid has waves: several scenes per slot
+    s = BatchSolver(prm)
+    base = s.solve(sc)
+    for n in (3, 12, 1000):
+        s.set_solve_share(n)
+        got = s.solve(sc)
+        for k in base:
+            assert np.array_equal(base[k], got[k]), (n, k)
+    with pytest.raises(SmpcError):
+        s.set_solve_share(0)
