@@ -269,7 +269,8 @@ def main():
     # the whole batch; results of step k land in result set k % streams.
     n_streams = max(1, args.streams)
     solvers = [BatchSolver(prm, device=local_rank) for _ in range(n_streams)]
-    hip_streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+    from nav2_social_mpc_controller_amd.episode import concurrent_streams
+    hip_streams = concurrent_streams(n_streams, device)  # streams that do not share a hardware queue (probed)
     for sv, st in zip(solvers, hip_streams):
         sv.set_stream(st.cuda_stream)
     solver = solvers[0]

@@ -14,7 +14,12 @@ sc = make_scenes(p, B, 8)
 sb, tens = sc.to_device()
 n = 4
 solvers = [BatchSolver(p) for _ in range(n)]
-streams = [torch.cuda.Stream() for _ in range(n)]
+import os
+if os.environ.get("PROBED_STREAMS") == "1":
+    from nav2_social_mpc_controller_amd.episode import concurrent_streams
+    streams = concurrent_streams(n, "cuda:0")
+else:
+    streams = [torch.cuda.Stream() for _ in range(n)]
 outs = []
 for s, st in zip(solvers, streams):
     s.set_stream(st.cuda_stream); outs.append(s.alloc_results(B, sc.T))
