@@ -23,6 +23,7 @@ else:
 outs = []
 for s, st in zip(solvers, streams):
     s.set_stream(st.cuda_stream); outs.append(s.alloc_results(B, sc.T))
+    if os.environ.get("SHARE"): s.set_solve_share(int(os.environ["SHARE"]))
 for i in range(n): solvers[i].solve_device(sb, outs[i][0])
 torch.cuda.synchronize()
 K = 24
