@@ -1,0 +1,45 @@
+"""Development soak: tests/test_gpu_parity.py::test_randomised_parameter_sets over many more seeds than the suite runs
+(random weights / horizons / block lengths / solver types / iteration caps / crowd sizes), one line per failing case.
+usage: python tools/gpu_soak.py [first_case=100] [cases=150]"""
+import sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import torch  # noqa: F401
+from conftest import cmd_err, well_conditioned
+from test_gpu_parity import _random_params, CMD_TOL, JAC_RTOL
+from nav2_social_mpc_controller_amd.scenes import make_scenes
+from nav2_social_mpc_controller_amd.solver import BatchSolver
+from oracle import oracle_py as O
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+bad = []
+worst = 0.0
+firm_total = scenes_total = 0
+t0 = time.time()
+for case in range(first, first + cases):
+    rng = np.random.default_rng(7000 + case)
+    prm = _random_params(rng)
+    N = int(rng.integers(1, 12))
+    sc = make_scenes(prm, 48, N, seed=8000 + case, map_cells=int(rng.choice([60, 120, 200])), n_valid=int(rng.integers(1, N + 1)))
+    s = BatchSolver(prm)
+    ev_o, ev_g = O.evaluate(prm, sc, sc.init_params), s.evaluate(sc, sc.init_params)
+    jerr = np.max(np.abs(ev_o["jacobian"] - ev_g["jacobian"]) / np.maximum(1.0, np.abs(ev_o["jacobian"])))
+    rz = O.solve(prm, sc, nthreads=16, theta_zero_convention=True)
+    rg = s.solve(sc)
+    stable = well_conditioned(O, prm, sc, rz, samples=4, nthreads=16, theta_zero_convention=True)
+    firm = (rz["marginal_decisions"] == 0) & stable
+    e = cmd_err(rg["cmds"], rz["cmds"])
+    problems = []
+    if not jerr < JAC_RTOL: problems.append(f"jacobian {jerr:.2e}")
+    if firm.any() and e[firm].max() > CMD_TOL: problems.append(f"dcmd {e[firm].max():.2e} on {(e[firm] > CMD_TOL).sum()} firm scenes")
+    if not np.array_equal(rg["iterations"][firm], rz["iterations"][firm]): problems.append("iterations differ on firm scenes")
+    if not np.array_equal(rg["status"][firm], rz["status"][firm]): problems.append("status differs on firm scenes")
+    if stable.mean() < 0.9: problems.append(f"only {stable.sum()}/48 well conditioned")
+    worst = max(worst, float(e[firm].max()) if firm.any() else 0.0)
+    firm_total += int(firm.sum()); scenes_total += 48
+    if problems:
+        bad.append(case)
+        print(f"case {case}: dims {prm.dims(sc.T)} N {N}: " + "; ".join(problems), flush=True)
+    if (case - first) % 25 == 24:
+        print(f"... {case - first + 1} cases, {len(bad)} with problems, worst firm dcmd {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+print(f"soak: {cases} cases from {first}: {len(bad)} with problems {bad}; firm scenes {firm_total}/{scenes_total}; worst |dcmd| on firm scenes {worst:.3e}")
