@@ -527,6 +527,7 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
   int G = 2;
   while (G < in->N + 1) G *= 2;
   p.G = G;
+  p.H = (2 * G <= smpc::kWave) ? 2 : 1;  // two copies of a scene split the partner rounds while they fit in the wavefront
   smpc::fill_math_table(&p.mt);
   p.max_time = in->max_time; p.time_step = in->time_step; p.od_resolution = in->od_resolution;
   p.od_shared = in->od_shared; p.od_width = in->od_width; p.od_height = in->od_height;
@@ -545,7 +546,7 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
     SMPC_TRY(st.out(error, B, &p.error));
   }
   if (B > 0) {
-    const int per_wave = smpc::kWave / G;
+    const int per_wave = smpc::kWave / (G * p.H);
     const int grid = (int)((B + per_wave - 1) / per_wave);
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(smpc::smpc_project_kernel, dim3(grid), dim3(smpc::kWave), 0, h->stream, p);

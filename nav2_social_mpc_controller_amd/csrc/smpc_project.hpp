@@ -2,7 +2,10 @@
 // (reference src/optimizer.cpp:554-728) with the Social Force Model of include/nav2_social_mpc_controller/sfm.hpp
 // (computeForces :462-485 = desired + obstacle + social force, group forces identically zero here; updatePosition
 // :525-551). One lane per agent (the robot is the last lane of the group), G = next power of two >= N+1 lanes per
-// scene, 64/G scenes per wavefront; other agents' states travel by wavefront shuffles; the T steps are sequential.
+// copy of a scene; while 2 G <= 64 a scene is held twice in the wavefront and the two copies split the partner rounds of
+// the social force between them (everything else they compute identically, so no state has to be exchanged besides the
+// two partial sums): the dependent chain of a step is what the kernel's time is made of, and this halves its longest
+// part. Other agents' states travel by wavefront shuffles; the T steps are sequential.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -14,7 +17,8 @@
 namespace smpc {
 
 struct ProjParams {
-  int B, T, N, G;
+  int B, T, N, G;  // G = lanes of one copy of a scene's agents (power of two >= N + 1)
+  int H;           // copies of a scene in the wavefront (2 when 2 G <= 64, else 1): each copy evaluates its share of the partner rounds
   float max_time, time_step, od_resolution;
   int od_shared, od_width, od_height;
   const double* init_people;
@@ -37,16 +41,24 @@ __device__ inline double proj_wrap(double a) {
   return a;
 }
 
-// computeObstacle (src/optimizer.cpp:673-728): nearest-obstacle lookup, float arithmetic as in the reference;
-// returns agent - obstacle (the reference stores this DIFFERENCE where the SFM expects a position).
+// computeObstacle (src/optimizer.cpp:673-728): nearest-obstacle lookup, float arithmetic as in the reference; the
+// result is agent - obstacle (the reference stores this DIFFERENCE where the SFM expects a position). In two parts so
+// that the grid load of a step is in flight during the next step's desired and social forces: `issue` finds the cell
+// and loads its entry, `finish` (called where the obstacle force needs it) turns the entry into the difference.
 template <typename PP>
-__device__ inline int proj_obstacle(const PP& p, const uint32_t* idx, double ox, double oy, double px, double py,
-                                    double& dx, double& dy) {
+__device__ inline int proj_obstacle_issue(const PP& p, const uint32_t* idx, double ox, double oy, double px, double py,
+                                          unsigned int& ob) {
   const double res = (double)p.od_resolution;
   const unsigned int xcell = (unsigned int)(long long)floor((px - ox) / res);
   const unsigned int ycell = (unsigned int)(long long)floor((py - oy) / res);
+  ob = 0;
   if (xcell >= (unsigned int)p.od_width || ycell >= (unsigned int)p.od_height) return SMPC_PROJ_CELL_OUT_OF_BOUNDS;
-  const unsigned int ob = idx[xcell + ycell * (unsigned int)p.od_width];
+  ob = idx[xcell + ycell * (unsigned int)p.od_width];
+  return SMPC_PROJ_OK;
+}
+template <typename PP>
+__device__ inline int proj_obstacle_finish(const PP& p, unsigned int ob, double ox, double oy, double px, double py,
+                                           double& dx, double& dy) {
   if (ob >= (unsigned int)p.od_width * (unsigned int)p.od_height) return SMPC_PROJ_INDEX_OUT_OF_BOUNDS;
   const unsigned int oyc = ob / (unsigned int)p.od_width, oxc = ob % (unsigned int)p.od_width;
   const float x = (float)((double)((float)oxc * p.od_resolution) + ox);
@@ -107,9 +119,11 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
   const auto& p = *(const ProjParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   const MathTabP mt = &p.mt;
   const int lane = threadIdx.x & 63;
-  const int G = p.G, T = p.T, N = p.N;
-  const int grp = lane / G, g = lane - grp * G, base = grp * G;
-  const int scene_raw = blockIdx.x * (64 / G) + grp;
+  const int G = p.G, H = p.H, T = p.T, N = p.N;
+  // a scene owns H x G lanes: H copies of its agents (copy hh = 0 writes the outputs), lane g of a copy = agent g
+  const int Gs = G * H;
+  const int grp = lane / Gs, hh = (lane - grp * Gs) / G, g = lane - grp * Gs - hh * G, base = grp * Gs + hh * G;
+  const int scene_raw = blockIdx.x * (64 / Gs) + grp;
   const bool live_scene = scene_raw < p.B;
   const size_t s = live_scene ? scene_raw : p.B - 1;
   const double* init = p.init_people + s * (size_t)N * 6;
@@ -122,7 +136,7 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
   const double kFd = 2.0, kFo = 20.0, kSig = 0.2, kRelax = 0.5;
 
   // people_traj[0] = init_people
-  if (live_scene)
+  if (live_scene && hh == 0)
     for (int q = g; q < N * 6; q += G) { const int a = q / 6, f = q - a * 6; out[(size_t)f * N + a] = init[a * 6 + f]; }
 
   // compact the valid agents: lane g holds the g-th valid one; lane n_valid holds the robot
@@ -138,7 +152,8 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
   double px = 0, py = 0, vx = 0, vy = 0, yaw = 0, lv = 0, av = 0, des = 0.6, radius = 0.5;
   double gx = 0, gy = 0, grad = 0.25, obx = 0, oby = 0;
   bool has_goal = false;
-  int err = SMPC_PROJ_OK;
+  int err = SMPC_PROJ_OK, ob_err = SMPC_PROJ_OK;
+  unsigned int ob = 0;  // grid entry of the agent's cell, loaded at the end of the previous step
   if (is_agent) {
     px = init[src * 6]; py = init[src * 6 + 1]; yaw = init[src * 6 + 2]; lv = init[src * 6 + 4]; av = init[src * 6 + 5];
     double sn, cs;
@@ -146,19 +161,25 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
     vx = lv * cs; vy = lv * sn;
     des = 0.5; radius = 0.5;
     gx = px + (double)p.max_time * vx; gy = py + (double)p.max_time * vy; has_goal = true;  // constant-velocity goal :588-592
-    const int e = proj_obstacle(p, idx, ox, oy, px, py, obx, oby);
-    if (e) err = e;
+    ob_err = proj_obstacle_issue(p, idx, ox, oy, px, py, ob);
+  }
+  // the robot's row of the coming step is loaded one step ahead (its latency would sit on every step's critical path)
+  double nr0 = 0, nr1 = 0, nr2 = 0, nr4 = 0, nr5 = 0, goal_x = 0, goal_y = 0;
+  if (is_robot) {
+    nr0 = rpath[0]; nr1 = rpath[1]; nr2 = rpath[2]; nr4 = rpath[4]; nr5 = rpath[5];
+    goal_x = rpath[(size_t)T * 6]; goal_y = rpath[(size_t)T * 6 + 1];
   }
   for (int i = 0; i < T; ++i) {
     if (is_robot) {  // the robot re-enters from the initial trajectory every step (:613-630)
-      const double* r = rpath + (size_t)i * 6;
-      px = r[0]; py = r[1]; yaw = r[2]; lv = r[4]; av = r[5];
+      px = nr0; py = nr1; yaw = nr2; lv = nr4; av = nr5;
+      const double* r = rpath + (size_t)min(i + 1, T - 1) * 6;
+      nr0 = r[0]; nr1 = r[1]; nr2 = r[2]; nr4 = r[4]; nr5 = r[5];
       double sn, cs;
       if (__builtin_expect(!(fabs(yaw) <= 1e5), 0)) sincos(yaw, &sn, &cs);
       else sincos_tab(mt, yaw, &sn, &cs);
       vx = lv * cs; vy = lv * sn;
       des = 0.6; radius = 0.5;
-      gx = rpath[(size_t)T * 6]; gy = rpath[(size_t)T * 6 + 1]; has_goal = true;
+      gx = goal_x; gy = goal_y; has_goal = true;
     }
     // ---- computeForces (sfm.hpp:462-485)
     double fx, fy;
@@ -176,15 +197,6 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
         fy = -vy / kRelax;
       }
     }
-    if (is_agent) {  // computeObstacleForce :207-235, one obstacle entry, used as a POSITION
-      const double mx = px - obx, my = py - oby;
-      const double z = mx * mx + my * my;
-      const double inv = rsqrt_pos(fmax(z, 1e-300));
-      const double mn = z * inv;
-      const double e = kFo * exp_tab(mt, -(mn - radius) * (1.0 / kSig));
-      fx += e * (z > 0 ? mx * inv : mx);
-      fy += e * (z > 0 ? my * inv : my);
-    }
     // computeSocialForce(index, agents) :237-281. The force on i from j is the exact negative of the force on j from i
     // (diff, velocity difference and with them the interaction vector flip sign; theta, B and both exponentials are
     // unchanged), so every unordered pair is evaluated once: in round k lane i takes partner (i + k) mod n and hands the
@@ -192,14 +204,16 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
     // The sum over partners runs in round order instead of index order (differences at round-off level).
     // Two rounds per trip: their evaluations are independent chains, so each lane keeps two in flight (the kernel runs
     // with two wavefronts per SIMD and is bound by the latency of one chain otherwise).
-    for (int kk = 1; 2 * kk <= n_act; kk += 2) {
-      const bool two = 2 * (kk + 1) <= n_act;
+    // Copy hh of the scene takes the rounds 1 + hh, 1 + hh + H, ...; the copies' sums are added below.
+    double ax = 0.0, ay = 0.0;  // this copy's share of the social force
+    for (int kk = 1 + hh; 2 * kk <= n_act; kk += 2 * H) {
+      const bool two = 2 * (kk + H) <= n_act;
       const bool act = g < n_act;
       double sfx[2], sfy[2];
       ProjPair q[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int k = (h == 1 && !two) ? kk : kk + h;
+        const int k = (h == 1 && !two) ? kk : kk + h * H;
         const int j = (g + k) % n_act;
         const double qx = __shfl(px, base + j, 64), qy = __shfl(py, base + j, 64);
         const double wx = __shfl(vx, base + j, 64), wy = __shfl(vy, base + j, 64);
@@ -210,20 +224,39 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
       if (__builtin_expect(q[0].near_axis || q[1].near_axis, 0)) { proj_pair_exact_theta(q[0]); proj_pair_exact_theta(q[1]); }
 #pragma unroll
       for (int h = 0; h < 2; ++h) proj_pair_end(mt, q[h], sfx[h], sfy[h]);
-      if (act) { fx += sfx[0]; fy += sfy[0]; }
+      if (act) { ax += sfx[0]; ay += sfy[0]; }
       if (2 * kk != n_act) {
         const int src = (g - kk + n_act) % n_act;
         const double rx = __shfl(sfx[0], base + src, 64), ry = __shfl(sfy[0], base + src, 64);
-        if (act) { fx -= rx; fy -= ry; }
+        if (act) { ax -= rx; ay -= ry; }
       }
       if (two) {
-        if (act) { fx += sfx[1]; fy += sfy[1]; }
-        if (2 * (kk + 1) != n_act) {
-          const int src = (g - kk - 1 + n_act) % n_act;
+        if (act) { ax += sfx[1]; ay += sfy[1]; }
+        if (2 * (kk + H) != n_act) {
+          const int src = (g - kk - H + 2 * n_act) % n_act;
           const double rx = __shfl(sfx[1], base + src, 64), ry = __shfl(sfy[1], base + src, 64);
-          if (act) { fx -= rx; fy -= ry; }
+          if (act) { ax -= rx; ay -= ry; }
         }
       }
+    }
+    if (H == 2) {  // both copies form the same sum (copy 0's share + copy 1's share), so they stay bit-identical
+      const double ox_ = __shfl_xor(ax, G, 64), oy_ = __shfl_xor(ay, G, 64);
+      ax = (hh == 0) ? ax + ox_ : ox_ + ax;
+      ay = (hh == 0) ? ay + oy_ : oy_ + ay;
+    }
+    fx += ax; fy += ay;
+    if (is_agent) {  // computeObstacleForce :207-235, one obstacle entry, used as a POSITION
+      // (after the social force in program order: the grid entry loaded at the end of the last step arrives meanwhile)
+      int oe = ob_err;
+      if (!oe) oe = proj_obstacle_finish(p, ob, ox, oy, px, py, obx, oby);
+      if (oe && !err) err = oe;
+      const double mx = px - obx, my = py - oby;
+      const double z = mx * mx + my * my;
+      const double inv = rsqrt_pos(fmax(z, 1e-300));
+      const double mn = z * inv;
+      const double e = kFo * exp_tab(mt, -(mn - radius) * (1.0 / kSig));
+      fx += e * (z > 0 ? mx * inv : mx);
+      fy += e * (z > 0 ? my * inv : my);
     }
     // ---- updatePosition (sfm.hpp:525-551)
     vx += fx * dt; vy += fy * dt;
@@ -247,11 +280,8 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
       if (proj_sqrt(ddx * ddx + ddy * ddy) <= grad) has_goal = false;
     }
     // ---- refresh each person's obstacle entry (:636-640) and emit people_traj[i+1] (:642-668)
-    if (is_agent) {
-      const int e = proj_obstacle(p, idx, ox, oy, px, py, obx, oby);
-      if (e && !err) err = e;
-    }
-    if (live_scene && g < N) {
+    if (is_agent) ob_err = proj_obstacle_issue(p, idx, ox, oy, px, py, ob);
+    if (live_scene && hh == 0 && g < N) {
       double* o = out + (size_t)(i + 1) * 6 * N + g;
       if (is_agent) {
         o[0] = px; o[N] = py; o[2 * N] = yaw; o[3 * N] = (double)((float)(i + 1) * p.time_step); o[4 * N] = lv; o[5 * N] = av;
@@ -260,14 +290,19 @@ __global__ __launch_bounds__(64) void smpc_project_kernel(const ProjParams) {
       }
     }
   }
+  if (is_agent) {  // the entry refreshed after the last step is checked like the others (:636-640)
+    int e = ob_err;
+    if (!e) e = proj_obstacle_finish(p, ob, ox, oy, px, py, obx, oby);
+    if (e && !err) err = e;
+  }
   // per-scene error: any agent lane that hit a grid exception
   int any = err;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     const int other = __shfl_xor(any, off, 64);
-    if (off < G && other && !any) any = other;
+    if (off < Gs && other && !any) any = other;
   }
-  if (live_scene && g == 0 && p.error) p.error[s] = any;
+  if (live_scene && g == 0 && hh == 0 && p.error) p.error[s] = any;
 }
 
 }  // namespace smpc
