@@ -30,6 +30,7 @@ extern "C" {
 
 #define SMPC_ABI_VERSION 3
 #define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20; every nb in 1..10 is instantiated */
+#define SMPC_MAX_LM_ITERATIONS 100000 /* smpc_create refuses a larger max_iterations: a persistent wave must reach its exit */
 #define SMPC_MAX_STEPS 63  /* T <= 63: one lane per pose of the rollout (T + 1 poses in a 64-lane wavefront) */
 #define SMPC_MAX_AGENTS 64 /* N <= 64: one bit per agent in the per-step validity mask */
 

@@ -402,6 +402,10 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
     set_error("Invalid parameter: linear_solver_type");  // same message as reference src/optimizer.cpp:44
     return nullptr;
   }
+  if (p->max_iterations < 0 || p->max_iterations > SMPC_MAX_LM_ITERATIONS) {
+    set_error("Invalid parameter: max_iterations (0 .. SMPC_MAX_LM_ITERATIONS)");
+    return nullptr;
+  }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) { set_error("no HIP device available (this library has no CPU fallback)"); return nullptr; }

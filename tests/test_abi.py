@@ -128,3 +128,15 @@ def test_block_limit_matches_the_header():
     assert lib.smpc_dims(C.byref(p), 40, 1, None, None, C.byref(nb), None, None, None) == 0 and nb.value == 11
     hip_src = open(os.path.join(ROOT, "nav2_social_mpc_controller_amd", "csrc", "smpc_hip.hip")).read()
     assert "case 10: return pick_w<10>" in hip_src and "case 11" not in hip_src
+
+
+def test_absurd_iteration_caps_are_refused_before_anything_is_launched():
+    """A persistent wave runs until its scenes stop: smpc_create refuses max_iterations outside 0 .. 100000 (the check
+    comes before the device query, so it is visible on a box without a GPU too)."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    src = open(HEADER).read()
+    cap = int(re.search(r"#define SMPC_MAX_LM_ITERATIONS (\d+)", src).group(1))
+    assert cap == 100000
+    for bad in (-1, cap + 1, 2 ** 31 - 1):
+        with pytest.raises(S.SmpcError, match="max_iterations"):
+            S.BatchSolver(OptimizerParams.readme().replace(max_iterations=bad))
