@@ -1,6 +1,6 @@
 """Development soak: tests/test_gpu_parity.py::test_randomised_parameter_sets over many more seeds than the suite runs
 (random weights / horizons / block lengths / solver types / iteration caps / crowd sizes), one line per failing case.
-usage: python tools/gpu_soak.py [first_case=100] [cases=150]"""
+usage: python tools/gpu_soak.py [first_case=100] [cases=150] [--wide]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -10,6 +10,21 @@ from test_gpu_parity import _random_params, CMD_TOL, JAC_RTOL
 from nav2_social_mpc_controller_amd.scenes import make_scenes
 from nav2_social_mpc_controller_amd.solver import BatchSolver
 from oracle import oracle_py as O
+WIDE = "--wide" in sys.argv  # shapes beyond the suite's generator: up to 10 parameter blocks, T up to 59, up to 40 agents
+sys.argv = [a for a in sys.argv if a != "--wide"]
+
+
+def wide_params(rng):
+    from test_gpu_parity import README
+    base = _random_params(rng)
+    bl = int(rng.integers(2, 6))
+    nb = int(rng.integers(5, 11))
+    mt = float(rng.choice([1.5, 2.0, 2.5, 3.0]))
+    T = int(round(mt / 0.05)) - 2
+    ch = min(nb * bl, T)  # control horizon inside the rollout
+    return base.replace(control_horizon=ch, parameter_block_length=bl, max_time=mt)
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 bad = []
@@ -18,8 +33,8 @@ firm_total = scenes_total = 0
 t0 = time.time()
 for case in range(first, first + cases):
     rng = np.random.default_rng(7000 + case)
-    prm = _random_params(rng)
-    N = int(rng.integers(1, 12))
+    prm = wide_params(rng) if WIDE else _random_params(rng)
+    N = int(rng.integers(1, 41 if WIDE else 12))
     sc = make_scenes(prm, 48, N, seed=8000 + case, map_cells=int(rng.choice([60, 120, 200])), n_valid=int(rng.integers(1, N + 1)))
     s = BatchSolver(prm)
     ev_o, ev_g = O.evaluate(prm, sc, sc.init_params), s.evaluate(sc, sc.init_params)
