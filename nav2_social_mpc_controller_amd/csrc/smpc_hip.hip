@@ -753,7 +753,13 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
     const dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(threads);
     const int need = (int)((L + smpc::kTrajGroup - 1) / smpc::kTrajGroup);
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
-    if (need > 32 || park > 48 * 1024) {
+    // plans over 512 poses: one-wavefront blocks of the 8-slot kernel with the reachable poses compacted into LDS
+    const size_t list_wave = (size_t)per_wave * 8 * smpc::kTrajGroup * 2 * sizeof(double);
+    if (need > 32 && park_wave + list_wave <= 48 * 1024) {
+      p.compact = 1;
+      hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel<8>, dim3((unsigned)((B + per_wave - 1) / per_wave)), dim3(smpc::kWave),
+                         park_wave + list_wave, h->stream, p);
+    } else if (need > 32 || park > 48 * 1024) {
       hipLaunchKernelGGL(smpc::smpc_trajectorize_long_kernel, dim3((unsigned)((B + per_wave - 1) / per_wave)), dim3(smpc::kWave), 0, h->stream, p);
     } else if (need <= 8) {
       hipLaunchKernelGGL(smpc::smpc_trajectorize_kernel<8>, grid, block, park, h->stream, p);

@@ -7,8 +7,10 @@
 //    squared-distance tests per lane + one 16-lane minimum; heading / bearing use the table functions of
 //    smpc_math.hpp; the steps' raw outputs are parked in LDS and written (with the quaternion round trip of the yaw)
 //    by all lanes after the walk.
-//  - smpc_trajectorize_long_kernel (longer plans, or more steps than the LDS park holds): the plan is searched where
-//    it lies, 64 poses per trip from its end, library functions.
+//    Longer plans take the same kernel after one pass that keeps the poses within reach of the start pose (only
+//    those can ever lie inside the look-ahead circle) in scan order.
+//  - smpc_trajectorize_long_kernel (more steps than the LDS park holds): the plan is searched where it lies, 64 poses
+//    per trip from its end, library functions.
 // Both keep the reference's scan order (first pose met inside the look-ahead circle when walking from the end of the
 // plan, else the closest one with the first-met tie rule).
 // Third-party arithmetic: angles::normalize_angle (ros/angles, version unpinned by the reference's package.xml) is
@@ -23,6 +25,7 @@ namespace smpc {
 
 struct TrajParams {
   int B, L, max_steps, omnidirectional;
+  int compact;  // register kernel: keep only the poses within reach of the start pose (plans longer than 16 kR poses)
   double desired_linear_vel, lookahead_dist, max_angular_vel, time_step;
   const double* plan;        // [B][L][2]
   const int32_t* plan_len;   // [B]
@@ -291,23 +294,64 @@ __global__ __launch_bounds__(kTrajBlock) void smpc_trajectorize_kernel(const Tra
     // pose Lp-1 - (16 u + gl) in slot u: walking u upwards, and lanes upwards inside a slot, is the reference's scan
     // from the end of the plan. Slots past the start of the plan hold +inf (never inside the circle, never closest).
     double px[kR], py[kR];
+    const double look = p.lookahead_dist, look2 = look * look;
+    const double look2_lo = look2 * (1.0 - 1e-12), look2_hi = look2 * (1.0 + 1e-12);
+    // Only a pose within look + max_steps |v| dt of the start pose can ever lie inside the look-ahead circle (the robot
+    // travels at most |v| dt per step).
+    const double reach = (fabs(look) + fabs(p.desired_linear_vel * p.time_step) * p.max_steps) * (1.0 + 1e-6) + 1e-9;
+    const double reach2 = reach * reach;
+    bool overflow = false;
+    if (!p.compact) {
 #pragma unroll
-    for (int u = 0; u < kR; ++u) {
-      const int i = Lp - 1 - (u * kTrajGroup + gl);
-      const double2 w = (i >= 0) ? *(const double2*)(plan + 2 * i) : make_double2(__builtin_inf(), __builtin_inf());
-      px[u] = w.x; py[u] = w.y;
+      for (int u = 0; u < kR; ++u) {
+        const int i = Lp - 1 - (u * kTrajGroup + gl);
+        const double2 w = (i >= 0) ? *(const double2*)(plan + 2 * i) : make_double2(__builtin_inf(), __builtin_inf());
+        px[u] = w.x; py[u] = w.y;
+      }
+    } else {
+      // A plan longer than the register file: one pass from its end keeps the reachable poses, in scan order, in an
+      // LDS list (the order is all the search needs: "first met from the end" = smallest list position); the slots
+      // are filled from the list. More reachable poses than slots: this plan's search reads the plan in memory.
+      double2* list = reinterpret_cast<double2*>(traj_park + (size_t)(blockDim.x / kTrajGroup) * p.max_steps * kTrajParkDoubles) +
+                      (size_t)bgrp * (kR * kTrajGroup);
+      int count = 0;
+      constexpr int kU = 8;  // 8 x 16 poses per trip: all loads of a trip are in flight before the first ballot
+      for (int base = Lp - 1; base >= 0; base -= kU * kTrajGroup) {
+        double2 w[kU];
+#pragma unroll
+        for (int v = 0; v < kU; ++v) {
+          const int i = base - v * kTrajGroup - gl;
+          w[v] = (i >= 0) ? *(const double2*)(plan + 2 * i) : make_double2(__builtin_nan(""), __builtin_nan(""));
+        }
+#pragma unroll
+        for (int v = 0; v < kU; ++v) {
+          const double z0 = (rx0 - w[v].x) * (rx0 - w[v].x) + (ry0 - w[v].y) * (ry0 - w[v].y);
+          const bool in = base - v * kTrajGroup - gl >= 0;
+          const bool cand = in && !(z0 > reach2);
+          const unsigned m = (unsigned)((__ballot(cand) >> (grp * kTrajGroup)) & 0xFFFFull);
+          const int pos = count + __popc(m & ((1u << gl) - 1u));
+          if (cand && pos < kR * kTrajGroup) list[pos] = w[v];
+          count += __popc(m);
+        }
+      }
+      overflow = count > kR * kTrajGroup;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int kept = min(count, kR * kTrajGroup);
+#pragma unroll
+      for (int u = 0; u < kR; ++u) {
+        const int j = u * kTrajGroup + gl;
+        const double2 w = (j < kept) ? list[j] : make_double2(__builtin_inf(), __builtin_inf());
+        px[u] = w.x; py[u] = w.y;
+      }
     }
     double rx = rx0, ry = ry0, rth = rth0;
     const double gx = plan[2 * (Lp - 1)], gy = plan[2 * (Lp - 1) + 1];
-    const double look = p.lookahead_dist, look2 = look * look;
-    const double look2_lo = look2 * (1.0 - 1e-12), look2_hi = look2 * (1.0 + 1e-12);
-    // Slots that can ever hold a pose inside the circle: the robot travels at most |v| dt per step, so a pose farther
-    // than look + max_steps |v| dt from the start pose is never inside it. One bit per slot, set when any lane of the
-    // wavefront holds a reachable pose there: the search of a step only visits those slots (2-3 of 25 for a 20 m plan).
+    // Slots that can ever hold a pose inside the circle: one bit per slot, set when any lane of the wavefront holds a
+    // reachable pose there: the search of a step only visits those slots (2-3 of 25 for a 20 m plan).
     uint32_t near_slots = 0;
     {
-      const double reach = (fabs(look) + fabs(p.desired_linear_vel * p.time_step) * p.max_steps) * (1.0 + 1e-6) + 1e-9;
-      const double reach2 = reach * reach;
 #pragma unroll
       for (int u = 0; u < kR; ++u) {
         const double z0 = (rx - px[u]) * (rx - px[u]) + (ry - py[u]) * (ry - py[u]);
@@ -340,7 +384,7 @@ __global__ __launch_bounds__(kTrajBlock) void smpc_trajectorize_kernel(const Tra
         }
       }
       int key = usel < 64 ? usel * kTrajGroup + gl : 0x7fffffff;
-      const bool exact = (__ballot(usel != usel_hi) >> (grp * kTrajGroup) & 0xFFFFull) != 0;
+      const bool exact = overflow || (__ballot(usel != usel_hi) >> (grp * kTrajGroup) & 0xFFFFull) != 0;
       if (exact) key = traj_first_inside_exact(plan, Lp, rx, ry, look, look2_lo, look2_hi, gl);
       key = traj_row_min(key);
       double wpx, wpy;

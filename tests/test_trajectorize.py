@@ -95,8 +95,9 @@ def test_pyref_edge_cases(hostlib):
 
 # (L, max_time): which kernel serves the call — plans in registers with 8 / 16 / 25 / 32 poses per lane in
 # four-wavefront blocks, one-wavefront blocks for long horizons (park of the step outputs in LDS), and the kernel that
-# searches the plan in memory (plans over 512 poses, horizons over 256 steps)
-TRAJ_SHAPES = [(100, 1.5), (160, 1.5), (390, 1.5), (500, 3.0), (600, 1.5), (160, 6.0), (120, 14.0)]
+# searches the plan in memory (horizons over 256 steps); plans over 512 poses: the 8-slot kernel after a pass that keeps
+# the poses within reach of the start pose (one plan of those cases is so dense that they do not fit: memory search)
+TRAJ_SHAPES = [(100, 1.5), (160, 1.5), (390, 1.5), (500, 3.0), (600, 1.5), (1500, 3.0), (160, 6.0), (120, 14.0), (700, 14.0)]
 
 
 @pytest.mark.gpu
@@ -116,6 +117,10 @@ def test_gpu_trajectorize_matches_pyref(omni, L, max_time):
     plan[11, :plan_len[11], 0] = 0.1 * np.arange(plan_len[11]); plan[11, :plan_len[11], 1] = 0.0
     pose[11] = [0.0, 0.0, 0.3]
     assert abs(np.hypot(*plan[11, 4]) - tp.lookahead_dist) < 1e-15
+    if L >= 600:  # 4 mm spacing: more poses within reach of the start than the compacted kernel has slots for
+        plan_len[13] = L
+        plan[13, :, 0], plan[13, :, 1] = 0.004 * np.arange(L), 0.0
+        pose[13] = [0.0, 0.0, 0.2]
     s = BatchSolver(OptimizerParams.readme())
     got = s.trajectorize(tp, plan, plan_len, pose)
     worst = 0.0

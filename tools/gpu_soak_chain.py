@@ -32,7 +32,7 @@ print(f"projection: {n_p} cases, worst difference {worst_p:.2e}, {time.time() - 
 worst_t = 0.0
 n_t = 0
 for omni in (False, True):
-    for L, max_time in ((60, 1.5), (160, 1.5), (390, 2.0), (500, 3.0)):
+    for L, max_time in ((60, 1.5), (160, 1.5), (390, 2.0), (500, 3.0), (1200, 2.0)):
         tp = params(omni, desired_linear_vel=0.6, max_time=max_time)
         for rep in range(max(1, seeds // 20)):
             B = 64
