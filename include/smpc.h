@@ -347,6 +347,39 @@ typedef struct smpc_trajectorize_out {
 
 int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* in, smpc_trajectorize_out* out);
 
+/* ---- the plan window of mpc::PathHandler::transformGlobalPlan (reference src/path_handler.cpp:39-108),
+ * the step of computeVelocityCommands in front of the trajectorizer (src/social_mpc_controller.cpp:176-180), for B
+ * robots: closest pose of the not yet pruned plan within `max_robot_pose_search_dist` of integrated path length (:56-66),
+ * poses from there up to the first one farther than `dist_threshold` from the robot (:68-75; the reference passes half
+ * the larger costmap side), moved into the costmap frame (:77-96) and the plan pruned up to the closest pose (:98).
+ * The reference's tf2 lookups are the caller's: `robot_pose` is the robot in the plan frame, `to_local` the rigid
+ * transform plan frame -> costmap frame per robot (NULL: the frames coincide). nav2_util's euclidean_distance /
+ * first_after_integrated_distance / min_by are restated in their ROS 2 Humble form (unpinned by the reference). */
+enum smpc_window_error {
+  SMPC_WINDOW_OK = 0,
+  SMPC_WINDOW_EMPTY_PLAN = 1,   /* "Received plan with zero length" (:44-47): nothing left of the plan */
+  SMPC_WINDOW_EMPTY_WINDOW = 2  /* "Resulting plan has 0 poses in it." (:100-103); the plan is pruned all the same */
+};
+
+typedef struct smpc_plan_window_batch {
+  int32_t B;
+  int32_t L;          /* row stride of `plan` and of the output window in poses */
+  int32_t on_device;  /* 0: host pointers, 1: device pointers; outputs follow */
+  int32_t reserved;
+  double max_robot_pose_search_dist;
+  double dist_threshold;
+  const double* plan;        /* [B][L][2] global plans as stored by setPlan (:110-113), plan frame */
+  const int32_t* plan_len;   /* [B] */
+  int32_t* plan_start;       /* [B] in / out: poses already erased by earlier calls (global_plan_.poses.erase, :98) */
+  const double* robot_pose;  /* [B][3] x, y, yaw in the plan frame */
+  const double* to_local;    /* [B][3] tx, ty, yaw of the plan frame in the costmap frame, or NULL */
+} smpc_plan_window_batch;
+
+/* window [B][L][2] (the first window_len[b] poses of row b are written), window_len [B], error [B] (enum
+ * smpc_window_error; may be NULL). The window is what smpc_trajectorize_path_batch takes as its plan. */
+int smpc_transform_global_plan_batch(smpc_handle* h, const smpc_plan_window_batch* in, double* window, int32_t* window_len,
+                                     int32_t* error);
+
 /* The command SocialMPCController::computeVelocityCommands returns (src/social_mpc_controller.cpp:176-256; SURVEY §8 row
  * f4) for B robots: cmds[0] of a usable solve (:250-256), the trajectorizer's first command when the optimisation was
  * not usable (:241-245) or — a limit of the fixed-T batch — when the trajectorized path was shorter than T + 1 poses,

@@ -168,6 +168,22 @@ class SmpcTrajectorizeBatch(C.Structure):
     ]
 
 
+class SmpcPlanWindowBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("L", C.c_int32),
+        ("on_device", C.c_int32),
+        ("reserved", C.c_int32),
+        ("max_robot_pose_search_dist", C.c_double),
+        ("dist_threshold", C.c_double),
+        ("plan", C.c_void_p),
+        ("plan_len", C.c_void_p),
+        ("plan_start", C.c_void_p),
+        ("robot_pose", C.c_void_p),
+        ("to_local", C.c_void_p),
+    ]
+
+
 class SmpcTrajectorizeOut(C.Structure):
     _fields_ = [
         ("path", C.c_void_p),
@@ -217,6 +233,7 @@ EXPORTED_SYMBOLS = [
     "smpc_format_to_optimize_batch",
     "smpc_memory_store_batch",
     "smpc_trajectorize_path_batch",
+    "smpc_transform_global_plan_batch",
     "smpc_select_command_batch",
     "smpc_math_probe",
     "smpc_fp64_peak_probe",

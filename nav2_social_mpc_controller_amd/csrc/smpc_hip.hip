@@ -17,6 +17,7 @@
 #include "smpc_project.hpp"
 #include "smpc_format.hpp"
 #include "smpc_trajectorize.hpp"
+#include "smpc_path_window.hpp"
 
 // ================================================================================================
 // Host side of the C ABI
@@ -780,6 +781,49 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
     SMPC_TRY(down(out->cmds_vy, p.cmds_vy, B * S1, h->stream));
     SMPC_TRY(down(out->n_poses, p.n_poses, B, h->stream));
     SMPC_TRY(down(out->error, p.error, B, h->stream));
+    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+  return SMPC_OK;
+}
+
+int smpc_transform_global_plan_batch(smpc_handle* h, const smpc_plan_window_batch* in, double* window, int32_t* window_len,
+                                     int32_t* error) {
+  if (!h || !in || !window || !window_len) { set_error("null handle / input / output"); return SMPC_ERR_INVALID_ARG; }
+  if (in->B < 0 || in->L < 1) { set_error("bad B / L"); return SMPC_ERR_INVALID_ARG; }
+  if (!in->plan || !in->plan_len || !in->plan_start || !in->robot_pose) { set_error("null input array"); return SMPC_ERR_INVALID_ARG; }
+  SMPC_HIP_CHECK(hipSetDevice(h->device));
+  const size_t B = in->B, L = in->L;
+  smpc::WindowParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.B = in->B; p.L = in->L; p.search_dist = in->max_robot_pose_search_dist; p.dist_threshold = in->dist_threshold;
+  Staging st(h);
+  if (in->on_device) {
+    p.plan = in->plan; p.plan_len = in->plan_len; p.plan_start = in->plan_start; p.robot_pose = in->robot_pose;
+    p.to_local = in->to_local; p.window = window; p.window_len = window_len; p.error = error;
+  } else {
+    const int32_t* start_in = nullptr;
+    SMPC_TRY(st.up(in->plan, B * L * 2, &p.plan, h->stream));
+    SMPC_TRY(st.up(in->plan_len, B, &p.plan_len, h->stream));
+    SMPC_TRY(st.up(static_cast<const int32_t*>(in->plan_start), B, &start_in, h->stream));
+    p.plan_start = const_cast<int32_t*>(start_in);  // device copy: read, updated in place, copied back below
+    SMPC_TRY(st.up(in->robot_pose, B * 3, &p.robot_pose, h->stream));
+    if (in->to_local) SMPC_TRY(st.up(in->to_local, B * 3, &p.to_local, h->stream));
+    SMPC_TRY(st.out(window, B * L * 2, &p.window));
+    SMPC_TRY(st.out(window_len, B, &p.window_len));
+    SMPC_TRY(st.out(error, B, &p.error));
+  }
+  if (B > 0) {
+    SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(smpc::smpc_plan_window_kernel, dim3((unsigned)B), dim3(smpc::kWave), 0, h->stream, p);
+    SMPC_HIP_CHECK(hipGetLastError());
+    SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+  }
+  if (!in->on_device) {
+    SMPC_TRY(down(window, p.window, B * L * 2, h->stream));
+    SMPC_TRY(down(window_len, p.window_len, B, h->stream));
+    SMPC_TRY(down(in->plan_start, static_cast<const int32_t*>(p.plan_start), B, h->stream));
+    SMPC_TRY(down(error, p.error, B, h->stream));
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   return SMPC_OK;

@@ -12,8 +12,8 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import (SmpcEvalOut, SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcParams, SmpcPeopleBatch, SmpcProjectionBatch,
-                   SmpcResultBatch, SmpcSceneBatch, SmpcTrajectorizeBatch, SmpcTrajectorizeOut)
+from ._abi import (SmpcEvalOut, SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcParams, SmpcPeopleBatch, SmpcPlanWindowBatch,
+                   SmpcProjectionBatch, SmpcResultBatch, SmpcSceneBatch, SmpcTrajectorizeBatch, SmpcTrajectorizeOut)
 from .params import OptimizerParams, TrajectorizerParams
 from .scenes import SceneBatch
 
@@ -71,6 +71,8 @@ def load_library():
     lib.smpc_memory_store_batch.restype = C.c_int
     lib.smpc_trajectorize_path_batch.argtypes = [C.c_void_p, C.POINTER(SmpcTrajectorizeBatch), C.POINTER(SmpcTrajectorizeOut)]
     lib.smpc_trajectorize_path_batch.restype = C.c_int
+    lib.smpc_transform_global_plan_batch.argtypes = [C.c_void_p, C.POINTER(SmpcPlanWindowBatch), C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.smpc_transform_global_plan_batch.restype = C.c_int
     lib.smpc_select_command_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
     lib.smpc_select_command_batch.restype = C.c_int
     lib.smpc_stage_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.c_void_p]
@@ -255,6 +257,35 @@ class BatchSolver:
             setattr(to, k, v.ctypes.data)
         _check(self.lib, self.lib.smpc_trajectorize_path_batch(self._h, C.byref(tb), C.byref(to)), "smpc_trajectorize_path_batch")
         return out
+
+    def transform_global_plan(self, plan: np.ndarray, plan_len: np.ndarray, plan_start: np.ndarray, robot_pose: np.ndarray,
+                              max_robot_pose_search_dist: float, dist_threshold: float, to_local: np.ndarray = None):
+        """PathHandler::transformGlobalPlan for B robots (smpc_transform_global_plan_batch): plan [B,L,2], plan_len [B],
+        plan_start [B] (updated in place: the pruning), robot_pose [B,3] in the plan frame, to_local [B,3] or None.
+        Returns dict(window [B,L,2], window_len [B], error [B])."""
+        plan = np.ascontiguousarray(plan, np.float64)
+        plan_len = np.ascontiguousarray(plan_len, np.int32)
+        assert plan_start.dtype == np.int32 and plan_start.flags.c_contiguous
+        robot_pose = np.ascontiguousarray(robot_pose, np.float64)
+        B, L, _ = plan.shape
+        wb = SmpcPlanWindowBatch()
+        wb.B, wb.L, wb.on_device = B, L, 0
+        wb.max_robot_pose_search_dist, wb.dist_threshold = float(max_robot_pose_search_dist), float(dist_threshold)
+        wb.plan, wb.plan_len, wb.plan_start, wb.robot_pose = plan.ctypes.data, plan_len.ctypes.data, plan_start.ctypes.data, robot_pose.ctypes.data
+        if to_local is not None:
+            to_local = np.ascontiguousarray(to_local, np.float64)
+            wb.to_local = to_local.ctypes.data
+        out = {"window": np.zeros((B, L, 2)), "window_len": np.zeros(B, np.int32), "error": np.zeros(B, np.int32)}
+        _check(self.lib, self.lib.smpc_transform_global_plan_batch(self._h, C.byref(wb), out["window"].ctypes.data,
+                                                                   out["window_len"].ctypes.data, out["error"].ctypes.data),
+               "smpc_transform_global_plan_batch")
+        return out
+
+    def transform_global_plan_device(self, wb: "SmpcPlanWindowBatch", window_ptr: int, window_len_ptr: int, error_ptr: int = 0):
+        assert wb.on_device == 1
+        _check(self.lib, self.lib.smpc_transform_global_plan_batch(self._h, C.byref(wb), C.c_void_p(window_ptr),
+                                                                   C.c_void_p(window_len_ptr), C.c_void_p(error_ptr)),
+               "smpc_transform_global_plan_batch")
 
     def trajectorize_device(self, tb: SmpcTrajectorizeBatch, to: SmpcTrajectorizeOut):
         assert tb.on_device == 1

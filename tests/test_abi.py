@@ -63,7 +63,8 @@ def test_next_row_struct_layouts_match_the_c_header(tmp_path):
               ("smpc_format_batch", _abi.SmpcFormatBatch, "memory"),
               ("smpc_format_out", _abi.SmpcFormatOut, "goal_yaw"),
               ("smpc_trajectorize_batch", _abi.SmpcTrajectorizeBatch, "robot_pose"),
-              ("smpc_trajectorize_out", _abi.SmpcTrajectorizeOut, "error")]
+              ("smpc_trajectorize_out", _abi.SmpcTrajectorizeOut, "error"),
+              ("smpc_plan_window_batch", _abi.SmpcPlanWindowBatch, "to_local")]
     body = "".join(f'printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {f}));\n' for c, _, f in probes)
     prog = tmp_path / "layout2.c"
     prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "smpc.h"\nint main(void){\n' + body + 'return 0;}\n')

@@ -1,0 +1,106 @@
+"""Plan window of the plugin shell: mpc::PathHandler::transformGlobalPlan — closest pose of the
+not yet pruned plan, window up to the costmap's half extent, rigid transform, pruning. Checker:
+oracle/pyref_path_handler.py (plain Python; nav2_util helpers restated from their published form). PARITY UNPINNED: the
+reference holds no fixtures for it."""
+import numpy as np
+import pytest
+
+
+def make_plans(seed, B, L):
+    """Arcs, some with a U-turn (the plan comes back past the robot: the integrated-distance bound is what keeps the
+    closest-pose search on the first leg), robots a little off the plan, some far off (empty window)."""
+    rng = np.random.default_rng(seed)
+    plan = np.zeros((B, L, 2))
+    plan_len = rng.integers(2, L + 1, size=B).astype(np.int32)
+    pose = np.zeros((B, 3))
+    for b in range(B):
+        x, y, th = rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(-np.pi, np.pi)
+        k, ds = rng.uniform(-0.3, 0.3), rng.uniform(0.03, 0.12)
+        turn = int(rng.integers(20, L)) if b % 3 == 0 else -1
+        pts = []
+        for i in range(L):
+            pts.append((x, y))
+            if i == turn:
+                th += np.pi - 0.05
+            x, y, th = x + ds * np.cos(th), y + ds * np.sin(th), th + k * ds
+        plan[b] = pts
+        j = int(rng.integers(0, max(1, min(plan_len[b], 60))))      # the robot is near pose j
+        off = rng.uniform(20, 30) if b % 11 == 5 else rng.uniform(0, 0.3)
+        pose[b] = [plan[b, j, 0] + off * np.cos(rng.uniform(0, 6.28)), plan[b, j, 1] + off * np.sin(rng.uniform(0, 6.28)), rng.uniform(-3, 3)]
+    return plan, plan_len, pose
+
+
+def check(got, plan, plan_len, start_before, start_after, pose, search, thr, to_local):
+    from oracle import pyref_path_handler as P
+    worst = 0.0
+    for b in range(plan.shape[0]):
+        win, ns, err = P.transform_global_plan(plan[b, :plan_len[b]], int(start_before[b]), pose[b], search, thr,
+                                               None if to_local is None else to_local[b])
+        assert got["error"][b] == err, (b, got["error"][b], err)
+        if err == P.EMPTY_PLAN:
+            assert start_after[b] == start_before[b] and got["window_len"][b] == 0
+            continue
+        assert start_after[b] == ns, (b, start_after[b], ns)
+        assert got["window_len"][b] == len(win), (b, got["window_len"][b], len(win))
+        if len(win):
+            worst = max(worst, float(np.max(np.abs(got["window"][b, :len(win)] - win))))
+    return worst
+
+
+def test_checker_on_a_straight_plan():
+    from oracle import pyref_path_handler as P
+    plan = np.stack([0.1 * np.arange(100), np.zeros(100)], 1)
+    win, start, err = P.transform_global_plan(plan, 0, (0.52, 0.2, 0.0), 1.0, 3.0)
+    assert err == 0 and start == 5 and len(win) == 31 and np.allclose(win[0], [0.5, 0.0]) and np.allclose(win[-1], [3.5, 0.0])
+    # the closest pose is only looked for within 1 m of path length from the pruned start
+    win, start, err = P.transform_global_plan(plan, 0, (2.03, 0.2, 0.0), 1.0, 3.0)
+    assert start == 10
+    assert P.transform_global_plan(plan, 100, (0, 0, 0), 1.0, 3.0)[2] == P.EMPTY_PLAN
+    w, s, e = P.transform_global_plan(plan, 0, (0.0, 50.0, 0.0), 1.0, 3.0)
+    assert e == P.EMPTY_WINDOW and s == 0 and len(w) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [40, 400, 1000])
+def test_gpu_plan_window_matches_the_checker(L):
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    s = BatchSolver(OptimizerParams.readme())
+    B = 150
+    plan, plan_len, pose = make_plans(40 + L, B, L)
+    rng = np.random.default_rng(L)
+    search, thr = 1.5, 4.0
+    start = np.zeros(B, np.int32)
+    start[7] = plan_len[7]                        # nothing left of this plan
+    for to_local in (None, np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-3, 3, B)], 1)):
+        for tick in range(3):                     # the same robots three times: pruning carries over
+            before = start.copy()
+            got = s.transform_global_plan(plan, plan_len, start, pose, search, thr, to_local)
+            worst = check(got, plan, plan_len, before, start, pose, search, thr, to_local)
+            assert worst <= 1e-12, worst
+            # the robots advance along their plans
+            nxt = np.minimum(start + 6, np.maximum(plan_len - 1, 0))
+            pose[:, :2] = plan[np.arange(B), nxt] + 0.05
+    assert (start > 0).sum() > B // 2
+    assert set(np.unique(got["error"])) >= {0, 1}
+
+
+@pytest.mark.gpu
+def test_gpu_plan_window_exact_distances():
+    """Distances that are exact in binary (3-4-5 triangles on a 1/8 m grid): the bound and threshold comparisons sit
+    exactly on representable values, where a different summation order or a different hypot would show."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    s = BatchSolver(OptimizerParams.readme())
+    L = 64
+    plan = np.zeros((4, L, 2))
+    plan[:, :, 0] = 0.125 * np.arange(L)
+    plan_len = np.full(4, L, np.int32)
+    pose = np.array([[0.0, 0.0, 0.0], [0.375, 0.5, 0.0], [1.0, 0.0, 0.0], [0.5, 0.0, 0.0]])   # pose 1: 3-4-5 to the poses +-0.375 away
+    start = np.zeros(4, np.int32)
+    search, thr = 1.0, 0.625                      # both exactly representable; sums of 0.125 are exact
+    before = start.copy()
+    got = s.transform_global_plan(plan, plan_len, start, pose, search, thr)
+    assert check(got, plan, plan_len, before, start, pose, search, thr, None) == 0.0
+    # integrated distance: 8 segments sum to exactly 1.0, which is not > 1.0: the 9th decides -> upper = 9 poses
+    assert list(start) == [0, 3, 8, 4]
