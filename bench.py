@@ -68,6 +68,11 @@ def algorithmic_bytes_per_sweep(N, T, P, M):
     return 8 * (6 * N * T + 2 * (T + 1) + P + 5) + 16 * T + 8 * (M * P + M)
 
 
+# PathHandler::transformGlobalPlan as the reference calls it: 4 m of path length for the closest-pose search
+# (src/social_mpc_controller.cpp:172), window up to half the costmap's larger side (src/path_handler.cpp:69-71: 20 m / 2)
+PLAN_WINDOW = (4.0, 10.0)
+
+
 def sharded_ticks(ShardedEpisode, shards, ticks, B, prm, scenes, curv, device_index, plan, plan_len, tp):
     """config.closed_loop.sharded; a failure (e.g. a driver that refuses the graph capture) is reported, not raised."""
     import numpy as np
@@ -75,7 +80,7 @@ def sharded_ticks(ShardedEpisode, shards, ticks, B, prm, scenes, curv, device_in
     try:
         se = ShardedEpisode(prm, scenes, curv, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]),
                             float(np.float32(0.1)), device=device_index, plan=plan, plan_len=plan_len, traj_params=tp,
-                            fov_angle=np.pi, shards=shards, graphs=True)
+                            fov_angle=np.pi, shards=shards, graphs=True, plan_window=PLAN_WINDOW)
         for _ in range(2):
             se.tick()
         se.synchronize()
@@ -111,7 +116,8 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
     plan, plan_len = arc_plans(scenes.pose0, curv, L=L)
     ep = BatchEpisode(prm, scenes, curv, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]),
                       float(np.float32(0.1)), device=device_index, plan=plan, plan_len=plan_len, traj_params=tp,
-                      fov_angle=np.pi)  # pi: everybody on the costmap is seen, the 8-agent workload of the headline config
+                      fov_angle=np.pi,  # pi: everybody on the costmap is seen, the 8-agent workload of the headline config
+                      plan_window=PLAN_WINDOW)
     for _ in range(2):
         ep.tick()
     ep.synchronize()
@@ -139,9 +145,10 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
         ms = tm[k + "_ms"]
         stages[k] = {"kernel_ms": ms, "algorithmic_GBps": B * alg[k] / (ms * 1e-3) / 1e9, "bytes_per_scene": alg[k]}
     stages["solve"] = {"kernel_ms": tm["solve_ms"]}
+    stages["plan_window"] = {"kernel_ms": tm["window_ms"]}
     return {"ticks_per_s": B / tick_s, "ms_per_tick": tick_s * 1e3, "ticks_timed": ticks,
             "sharded": sharded,
-            "chain": "trajectorize(f3) -> fov filter + people_to_status(f4, f2) -> format_to_optimize(f2) -> project_people(f1) "
+            "chain": "transformGlobalPlan(f4) -> trajectorize(f3) -> fov filter + people_to_status(f4, f2) -> format_to_optimize(f2) -> project_people(f1) "
                      "-> solve(a1-a12, people block staged inside) -> memory store(f2)",
             "stages": stages, "last_tick_failures": int((ep.res["status"] == 2).sum().item()),
             "projection_errors": int((ep.proj_error != 0).sum().item())}

@@ -348,7 +348,8 @@ typedef struct smpc_trajectorize_out {
 int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* in, smpc_trajectorize_out* out);
 
 /* ---- the plan window of mpc::PathHandler::transformGlobalPlan (reference src/path_handler.cpp:39-108),
- * the step of computeVelocityCommands in front of the trajectorizer (src/social_mpc_controller.cpp:176-180), for B
+ * the step of computeVelocityCommands in front of the trajectorizer (src/social_mpc_controller.cpp:171-180; the reference
+ * passes 4.0 m as the search distance, :172), for B
  * robots: closest pose of the not yet pruned plan within `max_robot_pose_search_dist` of integrated path length (:56-66),
  * poses from there up to the first one farther than `dist_threshold` from the robot (:68-75; the reference passes half
  * the larger costmap side), moved into the costmap frame (:77-96) and the plan pruned up to the closest pose (:98).

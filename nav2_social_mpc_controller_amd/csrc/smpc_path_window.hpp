@@ -1,6 +1,6 @@
 // smpc_path_window.hpp — SURVEY §8 row f4, the part of the plugin shell that is geometry rather than ROS plumbing:
 // mpc::PathHandler::transformGlobalPlan (reference src/path_handler.cpp:39-108) for B robots — the window of the global
-// plan that computeVelocityCommands hands to the trajectorizer (src/social_mpc_controller.cpp:176-180) and the pruning
+// plan that computeVelocityCommands hands to the trajectorizer (src/social_mpc_controller.cpp:171-180) and the pruning
 // of the poses the robot has passed. One wavefront per plan:
 //   A  first_after_integrated_distance (:56-59): segment lengths by all lanes, the running sum in the reference's own
 //      order (a uniform loop over the lanes' values: the comparison with the bound sees the very sums of the reference);

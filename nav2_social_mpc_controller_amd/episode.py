@@ -24,7 +24,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from ._abi import (SmpcFormatBatch, SmpcFormatOut, SmpcMemoryBatch, SmpcPeopleBatch, SmpcProjectionBatch, SmpcSceneBatch,
-                   SmpcTrajectorizeOut)
+                   SmpcTrajectorizeOut, SmpcPlanWindowBatch)
 from .params import OptimizerParams, TrajectorizerParams
 from .scenes import SceneBatch
 from .solver import BatchSolver
@@ -49,6 +49,9 @@ class TickRecord:
     memory_after: dict
     robot_pose: np.ndarray = None   # [B,3] pose the tick started from
     traj_n_poses: np.ndarray = None
+    window: np.ndarray = None       # [B,L,2] plan window handed to the trajectorizer (plan_window episodes)
+    window_len: np.ndarray = None
+    plan_start: np.ndarray = None   # [B] pruned start of every plan after this tick's window
     persons: np.ndarray = None      # [B,Np,5] world people (px, py, vx, vy, vz) the tick started from
     person_count: np.ndarray = None
     has_people: np.ndarray = None
@@ -58,11 +61,16 @@ class BatchEpisode:
     def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
                  od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
                  plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None,
-                 order_hint: bool = False):
+                 order_hint: bool = False, plan_window: tuple = None):
         """scenes: the start state (pose0, people at step 0, costmaps); w_ref [B]: curvature of the arc stand-in;
         od_*: one ObstacleDistance grid shared by all scenes. plan [B,L,2] + plan_len [B] + traj_params: global plans,
         trajectorized on the device every tick (the plan must stay longer than the horizon for the whole episode).
         fov_angle: field-of-view half angle of the people filter (reference default pi/4); None = no filter.
+        plan_window: (max_robot_pose_search_dist, dist_threshold): every tick starts with PathHandler::transformGlobalPlan
+        (smpc_transform_global_plan_batch; plan frame = costmap frame) and trajectorizes the window instead of the whole
+        plan, as computeVelocityCommands does (src/social_mpc_controller.cpp:171-180; the reference passes 4.0 m and half
+        the costmap's larger side); the plans are pruned as the robots
+        advance. None: the global plans go to the trajectorizer as they are.
         order_hint: hand the solve kernel's queue the scenes sorted by the previous tick's sweep counts, longest first
         (smpc_scene_batch.order; the results are the same, the lone launch is shorter)."""
         import torch
@@ -114,8 +122,15 @@ class BatchEpisode:
             self.traj_n = torch.zeros(B, dtype=torch.int32, device=self.dev)
             self.traj_err = torch.zeros(B, dtype=torch.int32, device=self.dev)
             self.traj_vy = torch.zeros((B, self.rows), **f64)
+            self.plan_window = plan_window
+            if plan_window is not None:
+                self.plan_start = torch.zeros(B, dtype=torch.int32, device=self.dev)
+                self.window = torch.zeros_like(self.plan)
+                self.window_len = torch.zeros(B, dtype=torch.int32, device=self.dev)
+                self.window_err = torch.zeros(B, dtype=torch.int32, device=self.dev)
         else:
             self.plan = None
+            self.plan_window = None
             self.rows = T + 1
         self.plan_path = torch.zeros((B, self.rows, 3), **f64)
         self.plan_cmds = torch.zeros((B, self.rows, 2), **f64)
@@ -138,11 +153,21 @@ class BatchEpisode:
         self.parked = None  # plan mode: scenes parked in the last tick (bool tensor)
 
     # -- trajectorizer (row f3) on the global plans, or the arc stand-in: v = 0.6, w = w_ref from the current pose --
-    def _plan(self):
+    def _plan(self, timing: dict = None):
         torch = self.torch
         if self.plan is not None:
             tb = self.solver.trajectorize_c(self.traj, self.B, int(self.plan.shape[1]), 1)
             tb.plan, tb.plan_len, tb.robot_pose = self.plan.data_ptr(), self.plan_len.data_ptr(), self.pose.data_ptr()
+            if self.plan_window is not None:  # the trajectorizer sees the window of the plan around the robot
+                wb = SmpcPlanWindowBatch()
+                wb.B, wb.L, wb.on_device = self.B, int(self.plan.shape[1]), 1
+                wb.max_robot_pose_search_dist, wb.dist_threshold = float(self.plan_window[0]), float(self.plan_window[1])
+                wb.plan, wb.plan_len, wb.plan_start = self.plan.data_ptr(), self.plan_len.data_ptr(), self.plan_start.data_ptr()
+                wb.robot_pose = self.pose.data_ptr()
+                self.solver.transform_global_plan_device(wb, self.window.data_ptr(), self.window_len.data_ptr(), self.window_err.data_ptr())
+                if timing is not None:
+                    timing["window_ms"] = self.solver.last_kernel_ms()
+                tb.plan, tb.plan_len = self.window.data_ptr(), self.window_len.data_ptr()
             to = SmpcTrajectorizeOut()
             to.path, to.cmds, to.cmds_vy = self.plan_path.data_ptr(), self.plan_cmds.data_ptr(), self.traj_vy.data_ptr()
             to.n_poses, to.error = self.traj_n.data_ptr(), self.traj_err.data_ptr()
@@ -176,13 +201,16 @@ class BatchEpisode:
                 return self.tick(record, timing)
         s, prm, B, T, N = self.solver, self.params, self.B, self.T, self.N
         pose_before = self.pose.cpu().numpy().copy() if record else None
-        self._plan()
+        self._plan(timing)
         if timing is not None and self.plan is not None:
             timing["trajectorize_ms"] = s.last_kernel_ms()
         rec = {}
         if record:
             if self.plan is not None:
                 rec.update(traj_n_poses=self.traj_n.cpu().numpy().copy())
+                if self.plan_window is not None:
+                    rec.update(window=self.window.cpu().numpy().copy(), window_len=self.window_len.cpu().numpy().copy(),
+                               plan_start=self.plan_start.cpu().numpy().copy())
             rec.update(robot_pose=pose_before, persons=self.persons.cpu().numpy().copy(),
                        person_count=self.person_count.cpu().numpy().copy())
         # 0. field-of-view filter + people_to_status
@@ -284,7 +312,7 @@ class BatchEpisode:
         self.gstream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
         self.gstream.wait_stream(torch.cuda.current_stream(self.dev))
         self.solver.set_stream(self.gstream.cuda_stream)
-        state = ("pose", "speed", "persons", "mem_path", "mem_cmds", "mem_valid", "order")
+        state = ("pose", "speed", "persons", "mem_path", "mem_cmds", "mem_valid", "order") + (("plan_start",) if self.plan_window is not None else ())
         with torch.cuda.stream(self.gstream):
             saved = {k: getattr(self, k).clone() for k in state}
             ticks = self.ticks
@@ -366,7 +394,8 @@ class ShardedEpisode:
     def __init__(self, params: OptimizerParams, scenes: SceneBatch, w_ref: np.ndarray, od_indexes: np.ndarray,
                  od_origin: np.ndarray, od_resolution: float, device: int = 0, plan: np.ndarray = None,
                  plan_len: np.ndarray = None, traj_params: TrajectorizerParams = None, fov_angle: float = None,
-                 shards: int = 3, order_hint: bool = False, graphs: bool = True, solve_share: int = None):
+                 shards: int = 3, order_hint: bool = False, graphs: bool = True, solve_share: int = None,
+                 plan_window: tuple = None):
         import torch
 
         self.torch = torch
@@ -382,7 +411,7 @@ class ShardedEpisode:
                 self.parts.append(BatchEpisode(
                     params, scenes.select(idx), np.asarray(w_ref)[idx], od_indexes, od_origin, od_resolution, device=device,
                     plan=None if plan is None else plan[idx], plan_len=None if plan_len is None else plan_len[idx],
-                    traj_params=traj_params, fov_angle=fov_angle, order_hint=order_hint))
+                    traj_params=traj_params, fov_angle=fov_angle, order_hint=order_hint, plan_window=plan_window))
         self.B = B
         self.graphs = graphs
         for part in self.parts:  # every shard's persistent solve grid takes its share of the resident wavefronts

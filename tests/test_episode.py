@@ -186,3 +186,39 @@ def test_sharded_episode_equals_the_single_chain():
     one.synchronize()
     sl = four.slices[1]
     assert np.array_equal(r.result["cmds"], one.res["cmds"].cpu().numpy()[sl])
+
+
+@pytest.mark.gpu
+def test_episode_with_the_plan_window_of_the_path_handler():
+    """computeVelocityCommands' order (src/social_mpc_controller.cpp:171-180): transformGlobalPlan, then trajectorize on
+    the window. Replayed on the CPU from what the device saw: window and pruning against pyref_path_handler, the
+    trajectorized path against pyref_trajectorize on that window."""
+    from nav2_social_mpc_controller_amd.episode import BatchEpisode, arc_plans
+    from nav2_social_mpc_controller_amd.params import OptimizerParams, TrajectorizerParams
+    from nav2_social_mpc_controller_amd.scenes import make_scenes, uniform
+    from oracle import pyref_path_handler, pyref_trajectorize
+
+    prm = OptimizerParams.readme()
+    tp = TrajectorizerParams(desired_linear_vel=0.6, lookahead_dist=0.4, max_angular_vel=1.0, time_step=0.05, max_time=1.5)
+    B, N = 24, 3
+    sc = make_scenes(prm, B, N, n_valid=2)
+    w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
+    plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)
+    search, thr = 2.0, 3.0
+    ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)),
+                      plan=plan, plan_len=plan_len, traj_params=tp, fov_angle=1.2, plan_window=(search, thr))
+    start = np.zeros(B, np.int32)
+    for tick in range(8):
+        r = ep.tick(record=True)
+        for s in range(B):
+            win, ns, err = pyref_path_handler.transform_global_plan(plan[s, :plan_len[s]], int(start[s]), r.robot_pose[s], search, thr)
+            assert err == 0 and r.plan_start[s] == ns and r.window_len[s] == len(win), (tick, s)
+            assert np.array_equal(r.window[s, :len(win)], win)
+            if s % 4 == 0:
+                p, c, terr = pyref_trajectorize.trajectorize(win, r.robot_pose[s], tp.omnidirectional, tp.desired_linear_vel,
+                                                             tp.lookahead_dist, tp.max_angular_vel, tp.time_step, tp.max_time)
+                assert terr == 0 and r.traj_n_poses[s] == p.shape[0]
+                assert np.max(np.abs(r.plan_path[s, :p.shape[0], :2] - p[:, :2])) <= 1e-11
+        start = r.plan_start.copy()
+        assert (ep.cmd_source.cpu().numpy() == 0).all()
+    assert start.max() >= 1 and (r.window_len < plan_len).all()   # the plans were pruned and clipped

@@ -1,5 +1,5 @@
 """Development probe: closed-loop batch episode throughput (format + project + solve + store per tick).
-usage: gpu_episode.py [B] [N] [ticks] [plan] [shard counts...]: a negative shard count replays HIP graphs, `0` skips the
+usage: gpu_episode.py [B] [N] [ticks] [plan|window] [shard counts...]: a negative shard count replays HIP graphs, `0` skips the
 sharded runs (single chain + stage times only), no count runs -2 -3 -4 and then the single chain."""
 import os, sys, time
 import numpy as np, torch
@@ -15,9 +15,11 @@ prm = OptimizerParams.readme()
 sc = make_scenes(prm, B, N)
 w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
 kw = {}
-if len(sys.argv) > 4 and sys.argv[4] == "plan":  # global plans trajectorized on the device every tick (row f3)
+if len(sys.argv) > 4 and sys.argv[4] in ("plan", "window"):  # global plans trajectorized on the device every tick (row f3)
     plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)
     kw = dict(plan=plan, plan_len=plan_len, traj_params=TrajectorizerParams(desired_linear_vel=0.6, max_time=prm.max_time))
+    if sys.argv[4] == "window":  # with PathHandler::transformGlobalPlan in front (row f4): 10 m = half the 20 m costmap
+        kw["plan_window"] = (10.0, 10.0)
 ep = BatchEpisode(prm, sc, w_ref, np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), 0.1, **kw)
 for _ in range(2):
     ep.tick()
