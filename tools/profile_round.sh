@@ -15,10 +15,10 @@ python3 tools/trace_extract.py $(find "$OUT/bench_trace" -name "*kernel_trace.cs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench1_trace" -- python3 bench.py --steps 10 --warmup 2 --streams 1 --no-cpu-baseline --no-extras > "$OUT/bench1_under_rocprof.json" 2> "$OUT/bench1_under_rocprof.err"
 cp $(find "$OUT/bench1_trace" -name "*kernel_stats.csv" | head -1) "$OUT/${TAG}_bench_streams1_kernel_stats.csv"
 # (3) the closed-loop chain (rows f1-f3 + solve + store) under the same tracer
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/episode_trace" -- python3 tools/gpu_episode.py 8192 8 10 plan 0 > "$OUT/episode_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/episode_trace" -- python3 tools/gpu_episode.py 8192 8 10 window 0 > "$OUT/episode_under_rocprof.log" 2>&1
 grep -E "^\"Name\"|smpc" $(find "$OUT/episode_trace" -name "*kernel_stats.csv" | head -1) > "$OUT/${TAG}_episode_kernel_stats.csv"
 # (3b) the same robots as three shards replayed from HIP graphs: begin / end of every kernel (overlap across streams)
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/episode3_trace" -- python3 tools/gpu_episode.py 8192 8 6 plan -3 > "$OUT/episode3_under_rocprof.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/episode3_trace" -- python3 tools/gpu_episode.py 8192 8 6 window -3 > "$OUT/episode3_under_rocprof.log" 2>&1
 python3 tools/trace_extract.py $(find "$OUT/episode3_trace" -name "*kernel_trace.csv" | head -1) | tail -70 > "$OUT/${TAG}_episode_sharded_trace.txt"
 # (4) PMC passes (separate runs, counters only)
 tools/prof_pmc.sh "$OUT/pmc" > /dev/null 2>&1
