@@ -104,3 +104,49 @@ def test_gpu_plan_window_exact_distances():
     assert check(got, plan, plan_len, before, start, pose, search, thr, None) == 0.0
     # integrated distance: 8 segments sum to exactly 1.0, which is not > 1.0: the 9th decides -> upper = 9 poses
     assert list(start) == [0, 3, 8, 4]
+
+
+def test_host_cpp_path_handler_matches_the_checker():
+    """host/path_handler.{hpp,cpp} (the reference's class and method names over plain structs, CPU) against the Python
+    checker: same window, same pruning, same exceptions, robot by robot, over three consecutive calls."""
+    import ctypes as C
+    import os
+    import subprocess
+
+    from oracle import pyref_path_handler as P
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "nav2_social_mpc_controller_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    lib = C.CDLL(os.path.join(host, "libsmpc_host.so"))
+    lib.smpc_host_transform_global_plan.restype = C.c_int
+    lib.smpc_host_transform_global_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_uint, C.c_uint, C.c_double,
+                                                    C.c_void_p, C.POINTER(C.c_int)]
+    B, L = 60, 300
+    plan, plan_len, pose = make_plans(77, B, L)
+    size, res = 80, 0.1                      # 8 m costmap: threshold 4 m
+    thr = max(size * res, size * res) / 2.0
+    start = np.zeros(B, np.int64)
+    seen = set()
+    for tick in range(3):
+        for b in range(B):
+            n = int(plan_len[b])
+            win, ns, err = P.transform_global_plan(plan[b, :n], int(start[b]), pose[b], 1.5, thr)
+            out = np.zeros((n, 2))
+            new_start = C.c_int(0)
+            xy = np.ascontiguousarray(pose[b, :2])
+            pl = np.ascontiguousarray(plan[b, :n])
+            rc = lib.smpc_host_transform_global_plan(pl.ctypes.data, n, int(start[b]), xy.ctypes.data, 1.5, size, size, res,
+                                                     out.ctypes.data, C.byref(new_start))
+            seen.add(err)
+            if err == P.EMPTY_PLAN:
+                assert rc == -1
+                continue
+            assert new_start.value == ns, (tick, b)
+            if err == P.EMPTY_WINDOW:
+                assert rc == -2
+            else:
+                assert rc == len(win) and np.array_equal(out[:rc], win), (tick, b)
+            start[b] = ns
+        nxt = np.minimum(start + 6, np.maximum(plan_len - 1, 0))
+        pose[:, :2] = plan[np.arange(B), nxt] + 0.05
+    assert {0, P.EMPTY_WINDOW} <= seen
