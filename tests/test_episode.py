@@ -168,7 +168,7 @@ def test_sharded_episode_equals_the_single_chain():
     w_ref = (uniform(0x5EED0001, np.arange(B), 6)[:, 0] * 2.0 - 1.0) * 0.6
     plan, plan_len = arc_plans(sc.pose0, 0.4 * w_ref)
     od = (np.zeros((480, 480), np.uint32), np.array([-16.0, -16.0]), float(np.float32(0.1)))
-    kw = dict(plan=plan, plan_len=plan_len, traj_params=tp, fov_angle=2.0)
+    kw = dict(plan=plan, plan_len=plan_len, traj_params=tp, fov_angle=2.0, plan_window=(4.0, 10.0))  # pruning state included
     one = BatchEpisode(prm, sc, w_ref, *od, **kw)
     four = ShardedEpisode(prm, sc, w_ref, *od, shards=4, graphs=True, **kw)  # every shard's tick replayed from a HIP graph
     assert [p.B for p in four.parts] == [50, 51, 51, 51]
@@ -178,7 +178,7 @@ def test_sharded_episode_equals_the_single_chain():
     one.synchronize()
     for name in ("status", "iterations", "cmds", "path", "final_cost"):
         assert np.array_equal(one.res[name].cpu().numpy(), four.gather(name).cpu().numpy()), name
-    for name in ("pose", "cmd_vel", "cmd_source", "proj_error"):
+    for name in ("pose", "cmd_vel", "cmd_source", "proj_error", "plan_start", "window_len"):
         assert np.array_equal(getattr(one, name).cpu().numpy(), four.gather(name).cpu().numpy()), name
     # a shard can still be ticked outside its graph (recording / per-stage timing): same numbers again
     one.tick()
@@ -222,3 +222,14 @@ def test_episode_with_the_plan_window_of_the_path_handler():
         start = r.plan_start.copy()
         assert (ep.cmd_source.cpu().numpy() == 0).all()
     assert start.max() >= 1 and (r.window_len < plan_len).all()   # the plans were pruned and clipped
+
+
+@pytest.mark.gpu
+def test_concurrent_streams_returns_distinct_streams():
+    import torch
+
+    from nav2_social_mpc_controller_amd.episode import concurrent_streams
+    for n in (1, 3, 4):
+        st = concurrent_streams(n, "cuda:0")
+        assert len(st) == n and len({s.cuda_stream for s in st}) == n
+        assert all(s.cuda_stream != torch.cuda.default_stream("cuda:0").cuda_stream for s in st)
