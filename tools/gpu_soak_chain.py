@@ -54,4 +54,28 @@ for omni in (False, True):
                     bad += 1
                     print(f"trajectorize omni={omni} L={L} max_time={max_time} seed {9000 + 100 * L + rep} plan {b}: ok={ok} diff {e:.2e}", flush=True)
 print(f"trajectorize: {n_t} plans, worst difference {worst_t:.2e}, {time.time() - t0:.0f} s")
+# plan window (PathHandler::transformGlobalPlan): tests/test_path_window.py's generator and checker over more seeds
+from test_path_window import make_plans as make_window_plans, check as check_window
+n_w = 0
+worst_w = 0.0
+for rep in range(max(1, seeds // 4)):
+    for L in (30, 256, 700):
+        B = 96
+        plan, plan_len, pose = make_window_plans(31000 + 17 * rep + L, B, L)
+        rng = np.random.default_rng(rep * 7 + L)
+        search, thr = float(rng.uniform(0.5, 6.0)), float(rng.uniform(1.0, 8.0))
+        to_local = None if rep % 2 else np.stack([rng.uniform(-2, 2, B), rng.uniform(-2, 2, B), rng.uniform(-3, 3, B)], 1)
+        start = np.zeros(B, np.int32)
+        for tick in range(3):
+            before = start.copy()
+            got = s.transform_global_plan(plan, plan_len, start, pose, search, thr, to_local)
+            try:
+                worst_w = max(worst_w, check_window(got, plan, plan_len, before, start, pose, search, thr, to_local))
+            except AssertionError as e:
+                bad += 1
+                print(f"plan window rep {rep} L={L} tick {tick}: {e}", flush=True)
+            n_w += B
+            nxt = np.minimum(start + 5, np.maximum(plan_len - 1, 0))
+            pose[:, :2] = plan[np.arange(B), nxt] + 0.04
+print(f"plan window: {n_w} calls, worst difference {worst_w:.2e}, {time.time() - t0:.0f} s")
 print(f"soak (chain): {bad} failing cases")
