@@ -25,6 +25,39 @@ SIMDS = 1024             # 256 CUs x 4 SIMDs
 VALU_CYCLES = 4          # cycles one wave64 VALU instruction occupies its SIMD (measured: SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N copies of this script, one rank per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), relay rank 0's
+    JSON line, and fail if any rank fails. Runs before anything touches the GPU: this process never initialises HIP."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMPC_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    line, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    for pr in procs[1:]:
+        try:
+            codes.append(pr.wait(timeout=600 if codes[0] == 0 else 30))
+        except subprocess.TimeoutExpired:  # a rank that outlives a failed rank 0 would wait in a collective for ever
+            pr.kill()
+            codes.append(pr.wait())
+    if any(c != 0 for c in codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return next(c for c in codes if c != 0) or 1
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    return 0
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -45,22 +78,35 @@ def usable_cores():
 
 def pmc_counters(kernel="smpc_solve_kernel"):
     """Per-launch PMC counters of `kernel` from the newest committed summary (profiles/rNN_pmc_summary.txt, made by
-    tools/profile_round.sh with separate --pmc passes). {} if unavailable."""
+    tools/profile_round.sh with separate --pmc passes) — but only if that summary was taken on the device sources this
+    process runs (`# csrc_digest:` line == buildinfo.csrc_digest()). Returns (counters, info); counters is {} when there
+    is no summary or it belongs to another build, and info says which."""
     import glob
     import re
+
+    from nav2_social_mpc_controller_amd.buildinfo import csrc_digest
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    here = csrc_digest()
     if not files:
-        return {}, None
+        return {}, {"file": None, "csrc_digest_running": here, "usable": False, "why": "no profiles/r*_pmc_summary.txt"}
     out = {}
     active = False
+    digest = None
     for line in open(files[-1]):
-        if line.startswith("=="):
+        if line.startswith("# csrc_digest:"):
+            digest = line.split(":", 1)[1].strip()
+        elif line.startswith("=="):
             active = kernel in line
         elif active:
             m = re.match(r"\s*(\w+)\s+mean/dispatch\s+([0-9.e+]+)", line)
             if m:
                 out[m.group(1)] = float(m.group(2))
-    return out, os.path.basename(files[-1])
+    info = {"file": os.path.basename(files[-1]), "csrc_digest_of_profile": digest, "csrc_digest_running": here,
+            "usable": digest == here}
+    if digest != here:
+        info["why"] = "the committed PMC summary was taken on other device sources: its instruction counts are not used"
+        return {}, info
+    return out, info
 
 
 def algorithmic_bytes_per_sweep(N, T, P, M):
@@ -220,6 +266,51 @@ def parity_sample(prm, scenes, got_cmds, n_sample, cores):
     return par, cpu_s
 
 
+def dry_run(args, rank, local_rank, world):
+    """`--dry-run`: the launch / rendezvous / reduction plumbing of the N > 1 path on CPU ranks (gloo), with NO solve at
+    all — not a measurement: value is null and the line says so. What it exercises is what an 8-GPU run adds to the
+    1-GPU run: rank spawn, barrier, MAX / SUM reductions of the summary, the all_gather of the parameter blocks and
+    rank 0's single JSON line. tests/test_bench_launch.py runs it with 2 ranks."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from nav2_social_mpc_controller_amd import dist as D
+
+    if os.environ.get("SMPC_BENCH_DRY_FAIL_RANK") == str(rank):
+        sys.exit(3)   # failure injection for the launcher test: a rank that dies must fail the whole command
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, P = args.batch, 6
+    lo, hi = D.weak_shard(B, rank)
+    params = torch.arange(lo, hi, dtype=torch.float64).unsqueeze(1).repeat(1, P)   # stand-in: rows tagged with scene ids
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))   # ranks finish at different times: the summary must carry the MAX
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64)
+    if dist.is_initialized():
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    summ = D.reduce_summary({"scenes": B, "max_rank": float(rank)})
+    g = D.gather_params(params).numpy()
+    line = None
+    if rank == 0:
+        line = {"metric": "MPC solves/sec (dry run of the launch path: nothing was solved)", "value": None, "unit": "solves/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "none", "dry_run": True,
+                "config": {"workload": "dry run (gloo, CPU ranks): spawn + barrier + reductions + all_gather only"},
+                "summary": summ, "elapsed_max_s": float(tmax.item()),
+                "gather": {"ranks_seen": int(g.shape[0]), "params_shape": list(g.shape),
+                           "first_scene_id_per_rank": [float(g[i, 0, 0]) for i in range(g.shape[0])],
+                           "distinct_rank_slices": int(len({hash(g[i].tobytes()) for i in range(g.shape[0])}))}}
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -233,8 +324,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra measurements in `config` (PCIe-inclusive, fixed-40, other shapes, closed loop): profiling runs")
     ap.add_argument("--streams", type=int, default=4,
-                    help="consecutive steps are issued round-robin on this many HIP streams (one solver handle each)")
+                    help="consecutive steps are issued round-robin on this many HIP streams (one solver handle and one "
+                         "scene batch of its own each)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the N-rank launch / reduction path on CPU ranks (gloo) without solving anything")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` launched plainly: become the launcher of N ranks (before any GPU call), relay rank 0's line
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # Only the JSON line may reach stdout: libraries underneath (RCCL prints a version banner at communicator creation)
     # write to file descriptor 1 too. Keep the real stdout aside and point fd 1 at stderr for the rest of the run.
@@ -242,19 +340,27 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    from nav2_social_mpc_controller_amd import dist as D
+    rank, local_rank, world = D.env_rank_world()
+    if args.dry_run:
+        line = dry_run(args, rank, local_rank, world)
+        if line is not None:
+            real_stdout.write(json.dumps(line) + "\n")
+            real_stdout.flush()
+        return
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from nav2_social_mpc_controller_amd import dist as D
     from nav2_social_mpc_controller_amd.params import OptimizerParams
     from nav2_social_mpc_controller_amd.scenes import make_scenes
     from nav2_social_mpc_controller_amd.solver import BatchSolver
 
-    rank, local_rank, world = D.env_rank_world()
     force_dist = os.environ.get("SMPC_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path with a single rank
     if args.gpus > 1 or world > 1 or force_dist:
-        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         try:
@@ -266,23 +372,27 @@ def main():
 
     prm = OptimizerParams.readme().replace(fixed_iterations=args.fixed_iterations)
     B, N = args.batch, args.people
+    n_streams = max(1, args.streams)
+    # Consecutive steps (independent batches of a serving stream) are issued round-robin on a few HIP streams, one
+    # solver handle each: the persistent solve kernel ends with a tail of a few long scenes (per-scene LM iteration
+    # counts vary 5..40), and the next batch's waves fill the CUs that the tail leaves idle. Every stream solves a scene
+    # batch of its OWN (scene ids disjoint across streams and ranks: 4 x 424 MB of inputs per GPU, more than the
+    # 256 MiB Infinity Cache holds), so no step finds its costmaps or people blocks warm from the step before;
+    # results of the steps of stream i land in result set i.
     lo, hi = D.weak_shard(B, rank)
-    scenes = make_scenes(prm, B, N, seed=0x5EED0001, first_scene=lo)
+    batches = [make_scenes(prm, B, N, seed=0x5EED0001, first_scene=lo + i * B * world) for i in range(n_streams)]
+    scenes = batches[0]
     T = scenes.T
     CH, bl, nb, P, M, _ = prm.dims(T, True)
 
-    # Consecutive steps (independent batches of a serving stream) are issued round-robin on a few HIP streams, one
-    # solver handle each: the persistent solve kernel ends with a tail of a few long scenes (per-scene LM iteration
-    # counts vary 5..40), and the next batch's waves fill the CUs that the tail leaves idle. Every step still solves
-    # the whole batch; results of step k land in result set k % streams.
-    n_streams = max(1, args.streams)
     solvers = [BatchSolver(prm, device=local_rank) for _ in range(n_streams)]
     from nav2_social_mpc_controller_amd.episode import concurrent_streams
     hip_streams = concurrent_streams(n_streams, device)  # streams that do not share a hardware queue (probed)
     for sv, st in zip(solvers, hip_streams):
         sv.set_stream(st.cuda_stream)
     solver = solvers[0]
-    sb, tens = scenes.to_device(device)
+    dev_batches = [sc.to_device(device) for sc in batches]
+    sb, tens = dev_batches[0]
     results = [sv.alloc_results(B, T, device) for sv in solvers]
     rb, out = results[0]
 
@@ -293,7 +403,7 @@ def main():
         torch.cuda.synchronize(device)
 
     for w in range(max(args.warmup, n_streams)):
-        solvers[w % n_streams].solve_device(sb, results[w % n_streams][0])
+        solvers[w % n_streams].solve_device(dev_batches[w % n_streams][0], results[w % n_streams][0])
     barrier()
     # HIP events around every step, recorded on the stream that step is launched on (begin .. end = staging pass + solve
     # kernel of that step): per-launch durations and the span of the timed region as the device saw it
@@ -301,10 +411,10 @@ def main():
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        st = hip_streams[k % n_streams]
-        ev0[k].record(st)
-        solvers[k % n_streams].solve_device(sb, results[k % n_streams][0])
-        ev1[k].record(st)
+        i = k % n_streams
+        ev0[k].record(hip_streams[i])
+        solvers[i].solve_device(dev_batches[i][0], results[i][0])
+        ev1[k].record(hip_streams[i])
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = np.array([ev0[k].elapsed_time(ev1[k]) for k in range(args.steps)])
@@ -312,20 +422,23 @@ def main():
     # per-launch device time of the solve kernel alone (library-side HIP events around its last launch per handle)
     solve_ms_each = [sv.last_kernel_ms() for sv in solvers[:min(n_streams, args.steps)]]
     solve_ms = float(sum(solve_ms_each) / len(solve_ms_each))
-    # an un-overlapped launch for reference (single stream, nothing else in flight)
+    # un-overlapped launches for reference (single stream, nothing else in flight): HIP events of the library around
+    # the solve kernel alone, the average over launches is what a `rocprofv3 --stats` of a one-stream run reports
     solo = []
-    for _ in range(3):
+    for _ in range(5):
         solver.solve_device(sb, rb)
         torch.cuda.synchronize(device)
         solo.append(solver.last_kernel_ms())
-    solo_ms = float(min(solo))
+    solo_ms = float(np.mean(solo[1:]))
+    solo_min_ms = float(min(solo))
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
 
-    evals = out["evaluations"].cpu().numpy().astype(np.int64)
+    evals_each = [r[1]["evaluations"].cpu().numpy().astype(np.int64) for r in results]
+    evals = evals_each[0]
     iters = out["iterations"].cpu().numpy()
     status = out["status"].cpu().numpy()
     local = {"scenes": B, "sweeps": int(evals.sum()), "iterations": int(iters.sum()),
@@ -342,7 +455,7 @@ def main():
     if not args.no_cpu_baseline:
         share = max(1, cores // max(1, world))
         n_sample = min(B, 512 * share) if world == 1 else min(B, 512)
-        par, cpu_s = parity_sample(prm, scenes, out["cmds"].cpu().numpy(), n_sample, share)
+        par, cpu_s = parity_sample(prm, scenes, out, n_sample, share)
     gathered = None
     if dist.is_initialized():
         if par is not None:
@@ -366,16 +479,17 @@ def main():
     keep = solver.stage_people_device(sb, device)
     stage_ms = solver.last_kernel_ms()
     k1 = []
-    for _ in range(8):
+    for _ in range(10):
         solver.eval_device(sb, tens["init_params"].data_ptr(), eo)
         k1.append(solver.last_kernel_ms())
-    k1_ms = float(np.median(k1[2:]))
+    k1_ms = float(np.mean(k1[2:]))       # the average launch, as a rocprofv3 --stats summary reports it
+    k1_min_ms = float(min(k1[2:]))
     eo.row_order = 0
     k1r = []
     for _ in range(5):
         solver.eval_device(sb, tens["init_params"].data_ptr(), eo)
         k1r.append(solver.last_kernel_ms())
-    k1_ref_order_ms = float(np.median(k1r[1:]))
+    k1_ref_order_ms = float(np.mean(k1r[1:]))
     sb.people_records, sb.people_aux = None, None
     del keep
 
@@ -383,26 +497,51 @@ def main():
         total_solves = summ["scenes"] * args.steps
         value = total_solves / elapsed_max
         bytes_sweep = algorithmic_bytes_per_sweep(N, T, P, M)
-        sweeps_per_launch = int(evals.sum())
-        bytes_launch = sweeps_per_launch * bytes_sweep
+        sweeps_each = [int(e.sum()) for e in evals_each]
+        sweeps_per_launch = float(np.mean(sweeps_each))        # the streams solve different scenes: mean over them
         eff_ms = elapsed_max / args.steps * 1e3          # what one launch costs the timed region
-        achieved = bytes_launch / (eff_ms * 1e-3) / 1e9
-        pmc, pmc_src = pmc_counters("smpc_solve_kernel")
-        traffic = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc else None
-        fp64 = None
         measured_peak = solver.fp64_peak_tflops()
+        # ---- the binding resource of the dominant kernel: FP64 VALU work / VALU instruction issue. Instruction counts per
+        # launch come from the committed PMC passes (same scenes as stream 0 of rank 0), accepted only for the very
+        # device sources running now and scaled by the sweeps this run's launches made; times are this run's.
+        pmc, pmc_info = pmc_counters("smpc_solve_kernel")
+        k1pmc, _ = pmc_counters("smpc_eval_kernel")
+        fp64 = None
+        top = {"bound": "fp64_valu", "kernel": "smpc_solve_kernel", "achieved": None, "peak": FP64_PEAK_TFS,
+               "unit": "TFLOP/s", "frac": None, "traffic": None}
         if all(k in pmc for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU")):
-            flop = 64.0 * (pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F64"])
-            fp64 = {"flop_per_launch_pmc": flop, "valu_instructions_per_launch_pmc": pmc["SQ_INSTS_VALU"],
-                    "achieved_TFs": flop / (eff_ms * 1e-3) / 1e12, "achieved_TFs_lone_launch": flop / (solo_ms * 1e-3) / 1e12,
-                    "peak": FP64_PEAK_TFS, "measured_peak_TFs": measured_peak,
-                    "frac": flop / (eff_ms * 1e-3) / 1e12 / FP64_PEAK_TFS,
+            scale = sweeps_per_launch / float(sweeps_each[0])   # PMC workload = stream 0's scenes
+            flop = 64.0 * (pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F64"]) * scale
+            valu = pmc["SQ_INSTS_VALU"] * scale
+            f64_instr = (pmc["SQ_INSTS_VALU_ADD_F64"] + pmc["SQ_INSTS_VALU_MUL_F64"] + pmc["SQ_INSTS_VALU_FMA_F64"]) * scale
+            fp64 = {"flop_per_launch": flop, "valu_instructions_per_launch": valu,
+                    "fp64_arithmetic_share_of_valu_instructions": f64_instr / valu,
+                    "achieved_TFs_overlapped": flop / (eff_ms * 1e-3) / 1e12,
+                    "achieved_TFs_lone_launch": flop / (solo_ms * 1e-3) / 1e12,
+                    "frac_of_78.6_overlapped": flop / (eff_ms * 1e-3) / 1e12 / FP64_PEAK_TFS,
+                    "frac_of_78.6_lone_launch": flop / (solo_ms * 1e-3) / 1e12 / FP64_PEAK_TFS,
+                    "measured_peak_TFs": measured_peak,
                     # every wave64 VALU instruction (FP64 or not) holds its SIMD for 4 cycles: the issue-slot view
-                    "valu_issue_frac": pmc["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * 2.4e9 * eff_ms * 1e-3),
-                    "valu_issue_frac_lone_launch": pmc["SQ_INSTS_VALU"] * VALU_CYCLES / (SIMDS * 2.4e9 * solo_ms * 1e-3),
-                    "note": "instruction / flop counts from the committed PMC passes of the same workload (%s); the issue "
-                            "fractions assume the 2.4 GHz the PMC passes show (GRBM_GUI_ACTIVE / 8 / duration)" % pmc_src}
+                    "valu_issue_frac_overlapped": valu * VALU_CYCLES / (SIMDS * 2.4e9 * eff_ms * 1e-3),
+                    "valu_issue_frac_lone_launch": valu * VALU_CYCLES / (SIMDS * 2.4e9 * solo_ms * 1e-3),
+                    "note": "counts: PMC passes committed in profiles/ for these very device sources (pmc.csrc_digest_*), scaled "
+                            "by sweeps; times: this run (overlapped = timed region / launches, lone = mean of lone launches "
+                            "by HIP events); issue fractions assume 2.4 GHz"}
+            top.update({"achieved": fp64["achieved_TFs_overlapped"], "frac": fp64["frac_of_78.6_overlapped"],
+                        "achieved_lone_launch": fp64["achieved_TFs_lone_launch"], "frac_lone_launch": fp64["frac_of_78.6_lone_launch"],
+                        "valu_issue_frac": fp64["valu_issue_frac_overlapped"],
+                        "valu_issue_frac_lone_launch": fp64["valu_issue_frac_lone_launch"]})
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # HBM-side bytes per solve launch (KiB counters; the solve kernel's reads are 32-byte records and unaligned
+            # dwords, not the 16 B / lane streaming pattern the guide's x2 FETCH_SIZE correction is calibrated on: reported
+            # as counted)
+            top["traffic"] = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         k1_achieved = B * bytes_sweep / (k1_ms * 1e-3) / 1e9
+        k1_traffic = None
+        if "FETCH_SIZE" in k1pmc and "WRITE_SIZE" in k1pmc:
+            # K1 streams its inputs 16 B / lane: FETCH_SIZE x 2 per the guide's gfx950 correction, WRITE_SIZE as counted
+            k1_traffic = (2.0 * k1pmc["FETCH_SIZE"] + k1pmc["WRITE_SIZE"]) * 1024.0
+        bytes_launch = sweeps_per_launch * bytes_sweep
         line = {
             "metric": "MPC solves/sec (horizon=18, 8 agents, max 40 LM iterations, Ceres termination rules)",
             "value": value, "unit": "solves/s",
@@ -413,25 +552,39 @@ def main():
                                    f"(T={T}, block=6, P={P}, M={M}), 200x200 u8 costmap per scene, DENSE_SCHUR, "
                                    f"max 40 LM iterations with Ceres termination rules"
                                    + (" DISABLED (fixed 40 iterations)" if args.fixed_iterations else "")
-                                   + f"; consecutive steps overlapped on {n_streams} HIP streams",
+                                   + f"; consecutive steps overlapped on {n_streams} HIP streams, every stream on a "
+                                     f"scene batch of its own",
                        "scenes_per_gpu": B, "people": N, "T": T, "P": P, "M": M, "streams": n_streams,
+                       "distinct_scene_batches": n_streams,
                        "single_stream_solves_per_s_per_gpu": B / (summ["max_solo_kernel_ms"] * 1e-3),
                        "mean_lm_iterations": summ["iterations"] / summ["scenes"],
                        "mean_sweeps_per_solve": summ["sweeps"] / summ["scenes"],
                        "status": {"convergence": int(summ["converged"]), "no_convergence": int(summ["no_convergence"]),
                                   "failure": int(summ["failed"])}},
-            "roofline": {
-                "bound": "fp64_valu_issue",
-                "bound_note": "the solve kernel is bound by VALU instruction issue (every wave64 VALU instruction holds its "
-                              "SIMD for 4 cycles; see fp64_valu.valu_issue_frac). The contract's algorithmic-HBM figures "
-                              "follow: achieved / peak / frac in GB/s; J never leaves the chip, so the measured HBM traffic "
-                              "is a fraction of the algorithmic bytes",
-                "contract_bound": "hbm", "kernel": "smpc_solve_kernel",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": pmc_src,
-                "algorithmic_bytes_per_launch": bytes_launch, "sweeps_per_launch": sweeps_per_launch, "bytes_per_sweep": bytes_sweep,
-                "launch_ms_effective": eff_ms,
-                "launch_ms_lone": solo_ms, "frac_lone_launch": bytes_launch / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "roofline": dict(top, **{
+                "bound_note": "binding resource of the dominant kernel (the fused solve): FP64 VALU work under VALU instruction "
+                              "issue; achieved = FP64 flop per launch / time per launch of THIS run (overlapped region; the "
+                              "lone-launch figures beside it), peak = datasheet FP64 vector rate. The solve never writes J, so "
+                              "its HBM traffic is a fraction of the contract's algorithmic bytes: the HBM figure of the "
+                              "contract is K1's, under `contract`",
+                "pmc": pmc_info,
+                "launch_ms_effective": eff_ms, "launch_ms_lone_mean": solo_ms, "launch_ms_lone_min": solo_min_ms,
+                "sweeps_per_launch": sweeps_per_launch, "sweeps_per_launch_by_stream": sweeps_each,
+                "fp64_valu": fp64,
+                "contract": {"bound": "hbm", "kernel": "smpc_eval_kernel (K1: the residual / Jacobian sweep, rows written)",
+                             "achieved": k1_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_achieved / HBM_PEAK_GBS,
+                             "traffic": k1_traffic,
+                             "launch_ms_mean": k1_ms, "launch_ms_min": k1_min_ms,
+                             "algorithmic_bytes_per_launch": B * bytes_sweep, "bytes_per_sweep": bytes_sweep,
+                             "input": "staged people block (smpc_stage_people_batch), critic-major rows (row_order 1)",
+                             "reference_row_order_launch_ms": k1_ref_order_ms,
+                             "reference_row_order_frac": B * bytes_sweep / (k1_ref_order_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "stage_people_kernel_ms": stage_ms,
+                             "wall_ms_from_reference_layout_people": float(min(k1_raw))},
+                # the solve's sweeps priced as if each wrote its Jacobian like K1 does (it does not): kept for continuity
+                # with earlier rounds, NOT a measured bandwidth
+                "frac_algorithmic_if_J_were_written": bytes_launch / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac_algorithmic_if_J_were_written_lone_launch": bytes_launch / (solo_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "timed_region_hip_events": {
                     "steps": args.steps, "span_ms": float(span_ms), "mean_step_ms": float(step_ms.mean()),
                     "min_step_ms": float(step_ms.min()), "max_step_ms": float(step_ms.max()),
@@ -439,15 +592,7 @@ def main():
                     "solve_kernel_ms_last_launch_per_stream": solve_ms_each,
                     "note": "begin / end events of every step on its own stream: a step (staging pass + solve kernel) lasts "
                             "mean_step_ms while steps_in_flight of them overlap; launch_ms_effective = span / steps is what one "
-                            "launch costs the region (rocprofv3 kernel trace of the same command: profiles/r02_bench_trace_*)"},
-                "fp64_valu": fp64,
-                "k1_sweep_kernel": {"launch_ms": k1_ms, "achieved": k1_achieved, "frac": k1_achieved / HBM_PEAK_GBS,
-                                    "input": "staged people block (smpc_stage_people_batch), critic-major rows (row_order 1)",
-                                    "reference_row_order_launch_ms": k1_ref_order_ms,
-                                    "reference_row_order_frac": B * bytes_sweep / (k1_ref_order_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "stage_people_kernel_ms": stage_ms,
-                                    "wall_ms_from_reference_layout_people": float(min(k1_raw)),
-                                    "bytes_per_sweep": bytes_sweep}},
+                            "launch costs the region (rocprofv3 kernel trace of the same command: profiles/r03_bench_trace_*)"}}),
         }
         if par is not None:
             line["parity"] = par
@@ -478,9 +623,9 @@ def main():
             # the other single-GPU BASELINE shapes, measured like the headline one but on one stream
             cfg5 = OptimizerParams.readme().replace(control_horizon=30, max_time=2.0)
 
-            def extra(name, fn, *a):  # an extra that fails is reported, it does not cost the headline line
+            def extra(name, fn, *a, **kw):  # an extra that fails is reported, it does not cost the headline line
                 try:
-                    line["config"][name] = fn(*a)
+                    line["config"][name] = fn(*a, **kw)
                 except Exception as e:  # noqa: BLE001
                     line["config"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -488,6 +633,8 @@ def main():
             extra("cfg2_8192", shape_record, OptimizerParams.readme(), 8192, 4, device, local_rank)
             extra("cfg5", shape_record, cfg5, 8192, 16, device, local_rank)
             extra("params_yaml_n3", shape_record, OptimizerParams.params_yaml(), 8192, 3, device, local_rank)
+            extra("soc_work_obst_benchmark_n3", shape_record, OptimizerParams.soc_work_obst_benchmark(), 8192, 3, device,
+                  local_rank, map_cells=OptimizerParams.BENCHMARK_COSTMAP_CELLS)
             extra("closed_loop", closed_loop_extras, prm, scenes, local_rank)
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()

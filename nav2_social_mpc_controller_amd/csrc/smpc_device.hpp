@@ -31,6 +31,7 @@ struct KParams {
   int B, T, N, CH, bl, nb, P, nbounded, nfeas;
   int size_x, size_y, costmap_shared;
   double dt, resolution;
+  double inv_resolution;  // 1 / resolution, rounded once on the host
   smpc_params prm;
   const double* pose0;
   const double* init_params;
@@ -270,8 +271,12 @@ __device__ inline Force social_force_general(double dx, double dy, double ux, do
 // to the discontinuity of sign(theta) the reference's own two-atan2 form decides, :198-200).
 // pair_force(-d, -u) == -pair_force(d, u) bit for bit (every intermediate flips sign or stays exactly), with equal
 // derivatives: the force on an agent from the robot needs no evaluation of its own.
+// The constant factors are left to the caller, who applies them once to the sums over the agents of a step instead of
+// to every pair: the force and its diff-derivatives come WITHOUT the factor k (kPairForceK), the u-derivatives without
+// k * lambda (kPairForceLambda; u enters the interaction vector as lambda u).
+constexpr double kPairForceK = 2.1, kPairForceLambda = 2.0;
 __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux, double uy) {
-  const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, nn = 2.0, k = 2.1;
+  const double lambda = kPairForceLambda, gamma = 0.35, nPrime = 3.0, nn = 2.0;
   Force R;
   const double d2 = fma(dx, dx, dy * dy);
   const double inv_n = rsqrt_pos(d2);
@@ -300,8 +305,8 @@ __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux,
   __builtin_amdgcn_sched_barrier(0);
   const double fv = -E1;
   const double fa = (phi > 0.0) ? -E2 : E2;  // -sign(theta) E2, sign = -1 at theta == 0 (:210)
-  R.fx = k * (fv * ix - fa * iy);  // :218-224, i_perp = (-iy, ix)
-  R.fy = k * (fv * iy + fa * ix);
+  R.fx = fma(fv, ix, -(fa * iy));  // :218-224 without the factor k, i_perp = (-iy, ix)
+  R.fy = fma(fv, iy, fa * ix);
   // derivative: see social_force_general(); dfa = sgn E2 (...) = -fa (...)
   const double nB2 = n * inv_B * inv_B;
   const double anx = -inv_B * R.fx, any = -inv_B * R.fy;
@@ -311,8 +316,8 @@ __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux,
   {
     const double dfv = E1 * (g1 * twoB);
     const double dfa = -fa * (g2 * twoB);
-    aax = k * (dfv * ix - dfa * iy);
-    aay = k * (dfv * iy + dfa * ix);
+    aax = fma(dfv, ix, -(dfa * iy));
+    aay = fma(dfv, iy, dfa * ix);
   }
   auto column = [&](double dL, double kappa, double& ofx, double& ofy) {
     const double dB = gamma * dL;
@@ -321,14 +326,14 @@ __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux,
     const double dfv = fv * fma(-g1, common, dbase);
     const double dfa = fa * fma(-g2, common, dbase);
     const double ci = fma(-fa, kappa, dfv), cp = fma(fv, kappa, dfa);
-    ofx = k * (ci * ix - cp * iy);
-    ofy = k * (ci * iy + cp * ix);
+    ofx = fma(ci, ix, -(cp * iy));
+    ofy = fma(ci, iy, cp * ix);
   };
   double axx, axy, ayx, ayy;
   column(ix, -iy * inv_L, axx, axy);
   column(iy, ix * inv_L, ayx, ayy);
-  R.dfx_dux = lambda * axx; R.dfy_dux = lambda * axy;
-  R.dfx_duy = lambda * ayx; R.dfy_duy = lambda * ayy;
+  R.dfx_dux = axx; R.dfy_dux = axy;  // without the factor k * lambda
+  R.dfx_duy = ayx; R.dfy_duy = ayy;
   const double cx = aax - ey * axx + ex * ayx, cy = aay - ey * axy + ex * ayy;
   const double da1 = -ey * inv_n, da2 = ex * inv_n;
   R.dfx_dx = ex * anx + da1 * cx; R.dfy_dx = ex * any + da1 * cy;
@@ -358,10 +363,32 @@ struct CostPatch {
   uint32_t sh;       // bit offsets (0, 8, 16, 24) of the four taps inside a row dword, 5 bits each
 };
 
+// Integer cell of a coordinate, kept defined for wild values (clamping below makes any far-outside index equivalent).
+__device__ inline int cell_index(double v, int size) { return (int)fmin(fmax(floor(v), -4.0), (double)size + 4.0); }
+
+// true when the whole 4 x 4 patch around (r, c) lies inside the map: no tap is clamped (NaN coordinates: false)
+__device__ inline bool bicubic_interior(int size_x, int size_y, double r, double c) {
+  const int row = cell_index(r, size_y), col = cell_index(c, size_x);
+  return (row >= 1) & (row <= size_y - 3) & (col >= 1) & (col <= size_x - 3);
+}
+
+// kInterior: the caller has established bicubic_interior() for EVERY lane of the wave (a wave-uniform decision: the
+// clamps, the per-tap bit offsets and their variable shifts — ~90 integer instructions per sweep — are then skipped;
+// the taps and the arithmetic on them are the same, so the result does not depend on which path a wave takes).
+template <bool kInterior>
 __device__ inline void bicubic_fetch(const uint8_t* __restrict__ map, int size_x, int size_y, double r, double c, CostPatch& p) {
-  const double fr = floor(r), fc = floor(c);
-  const double frc = fmin(fmax(fr, -4.0), (double)size_y + 4.0), fcc = fmin(fmax(fc, -4.0), (double)size_x + 4.0);
-  const int row = (int)frc, col = (int)fcc;
+  const int row = cell_index(r, size_y), col = cell_index(c, size_x);
+  if (kInterior) {
+    const uint8_t* q = map + (size_t)(row - 1) * size_x + (col - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t v;
+      __builtin_memcpy(&v, q + (size_t)i * size_x, 4);  // unaligned dword
+      p.row[i] = v;
+    }
+    p.sh = 0u | (8u << 5) | (16u << 10) | (24u << 15);
+    return;
+  }
   const int start = min(max(col - 1, 0), size_x - 4);
   uint32_t sh = 0;
 #pragma unroll
@@ -377,6 +404,7 @@ __device__ inline void bicubic_fetch(const uint8_t* __restrict__ map, int size_x
 }
 
 // (r, c) must be the coordinates the patch was fetched for
+template <bool kInterior>
 __device__ inline void bicubic_eval(const CostPatch& p, double r, double c, double& f, double& dfdr, double& dfdc) {
   const double tr = r - floor(r), tc = c - floor(c);
   double fv[4], dv[4];
@@ -384,7 +412,10 @@ __device__ inline void bicubic_eval(const CostPatch& p, double r, double c, doub
   for (int i = 0; i < 4; ++i) {
     double t[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = (double)((p.row[i] >> ((p.sh >> (5 * j)) & 31u)) & 0xffu);
+    for (int j = 0; j < 4; ++j) {
+      if (kInterior) t[j] = (double)((p.row[i] >> (8 * j)) & 0xffu);
+      else t[j] = (double)((p.row[i] >> ((p.sh >> (5 * j)) & 31u)) & 0xffu);
+    }
     cubic_hermite(t[0], t[1], t[2], t[3], tc, fv[i], dv[i]);
   }
   double unused;
@@ -655,20 +686,29 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   const int t1 = min(sl + 1, T);
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
   // a5 obstacle: the costmap patch under the front point is requested now and used after the agent loop
+  // cell coordinates of the front point: (front - origin) / resolution (critics/obstacle_cost_function.hpp:154-158) as a
+  // product with the host-rounded reciprocal (within an ulp of the quotient; the interpolant is C1, so an ulp of its
+  // argument is an ulp of its value)
   const bool wide_map = k.size_x >= 4;
   CostPatch patch;
+  bool patch_interior = false;  // wave-uniform
   if (wide_map) {
-    const double ob_ic = (X + 0.25 * c1 - cst[4]) / k.resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) / k.resolution;
-    bicubic_fetch(c.map, k.size_x, k.size_y, ob_ir, ob_ic, patch);
+    const double ob_ic = (X + 0.25 * c1 - cst[4]) * k.inv_resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) * k.inv_resolution;
+    patch_interior = __all(bicubic_interior(k.size_x, k.size_y, ob_ir, ob_ic));
+    if (patch_interior) bicubic_fetch<true>(c.map, k.size_x, k.size_y, ob_ir, ob_ic, patch);
+    else bicubic_fetch<false>(c.map, k.size_x, k.size_y, ob_ir, ob_ic, patch);
   }
 
   SMPC_STAMP(c, 2);
   // ---- a3 social work + a4 proxemics: walk the agents of step sl
-  double soc[kSoc];
-#pragma unroll
-  for (int i = 0; i < kSoc; ++i) soc[i] = 0.0;
+  // what leaves this block is the finished social-work critic (residual and state-space gradient) and the nearest
+  // valid agent of the proxemics critic: eight values across the divergent branch instead of the 23 running sums
+  double sw_r = 0.0, sw_gx = 0.0, sw_gy = 0.0, sw_gt = 0.0, sw_gv = 0.0;
   double pbest = 1.7976931348623157e308, pdx = 0.0, pdy = 0.0;
   if (c.has_people) {
+    double soc[kSoc];
+#pragma unroll
+    for (int i = 0; i < kSoc; ++i) soc[i] = 0.0;
     double su[4] = {0.0, 0.0, 0.0, 0.0};  // sums over valid agents of dF/du: (fx,ux) (fy,ux) (fx,uy) (fy,uy)
     double qh[4] = {0.0, 0.0, 0.0, 0.0};  // sums over pairs of F . dF/d(x, y, ux, uy), agent side
     const MathTabP mt = &k.mt;
@@ -708,6 +748,15 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       qh[1] = fma(F.fx, F.dfx_dy, fma(F.fy, F.dfy_dy, qh[1]));
       qh[2] = fma(F.fx, F.dfx_dux, fma(F.fy, F.dfy_dux, qh[2]));
       qh[3] = fma(F.fx, F.dfx_duy, fma(F.fy, F.dfy_duy, qh[3]));
+    }
+    {  // the constant factors pair_force() leaves out, once per step instead of once per pair
+      const double kk = kPairForceK, kl = kPairForceK * kPairForceLambda, k2 = kPairForceK * kPairForceK,
+                   k2l = kPairForceK * kPairForceK * kPairForceLambda;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) soc[i] *= kk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) su[i] *= kl;
+      soc[10] *= k2; qh[0] *= k2; qh[1] *= k2; qh[2] *= k2l; qh[3] *= k2l;
     }
     if (__builtin_expect(redo, 0)) {
       // Rare: this lane met a pair the fast form does not cover. It walks its agents again in the general form (both
@@ -758,6 +807,14 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     soc[12] += 2.0 * qh[1];
     soc[13] += 2.0 * (vb * (-s1 * qh[2] + c1 * qh[3]));
     soc[14] += 2.0 * (c1 * qh[2] + s1 * qh[3]);
+    // a3 social work: w (|sum F|^2 + sum |G|^2 + 1e-6), critics/social_work_cost_function.hpp:125-147
+    const double wsoc = k.prm.socialwork_w;
+    const double wr = soc[0] * soc[0] + soc[1] * soc[1];
+    sw_r = wsoc * (wr + soc[10] + 1e-6);
+    sw_gx = wsoc * (2.0 * (soc[0] * soc[2] + soc[1] * soc[3]) + soc[11]);
+    sw_gy = wsoc * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
+    sw_gt = wsoc * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
+    sw_gv = wsoc * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
   }
 
   SMPC_STAMP(c, 3);
@@ -873,22 +930,15 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         gth = w.agent_angle_w * 2.0 * ad;
       }
       if (kRows) emit(0, live, people, r, 0.0, 0.0, gth, 0.0);
-      else {
-        r = people ? r : 0.0; gth = people ? gth : 0.0;  // a slot without people beside one with people
+      else {  // (a slot without people beside one with people has no steering target: r = gth = 0 already)
         Att = fma(gth, gth, Att); bt = fma(gth, r, bt); cc = fma(r, r, cc);
       }
     }
-    // a3 social work: w (|sum F|^2 + sum |G|^2 + 1e-6)
+    // a3 social work (finished inside the agent block above; zero for a slot without people)
     {
-      const double wr = soc[0] * soc[0] + soc[1] * soc[1];
-      double r = w.socialwork_w * (wr + soc[10] + 1e-6);
-      double gx = w.socialwork_w * (2.0 * (soc[0] * soc[2] + soc[1] * soc[3]) + soc[11]);
-      double gy = w.socialwork_w * (2.0 * (soc[0] * soc[4] + soc[1] * soc[5]) + soc[12]);
-      double gt = w.socialwork_w * (2.0 * (soc[0] * soc[6] + soc[1] * soc[7]) + soc[13]);
-      double gv = w.socialwork_w * (2.0 * (soc[0] * soc[8] + soc[1] * soc[9]) + soc[14]);
+      const double r = sw_r, gx = sw_gx, gy = sw_gy, gt = sw_gt, gv = sw_gv;
       if (kRows) emit(1, live, people, r, gx, gy, gt, gv);
       else {
-        r = people ? r : 0.0; gx = people ? gx : 0.0; gy = people ? gy : 0.0; gt = people ? gt : 0.0; gv = people ? gv : 0.0;
         Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Axt = fma(gx, gt, Axt); Axv = fma(gx, gv, Axv);
         Ayy = fma(gy, gy, Ayy); Ayt = fma(gy, gt, Ayt); Ayv = fma(gy, gv, Ayv);
         Att = fma(gt, gt, Att); Atv = fma(gt, gv, Atv); Avv = fma(gv, gv, Avv);
@@ -900,14 +950,13 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       const double e = 3.0 * exp_tab(&k.mt, -pbest / (0.5 * 0.5));
       double r = w.proxemics_w * e;
       double gx = r * (-2.0 * pdx / (0.5 * 0.5)), gy = r * (-2.0 * pdy / (0.5 * 0.5));
-      if (pbest == 1.7976931348623157e308) {
+      if (people && pbest == 1.7976931348623157e308) {
         // no valid agent: the reference's dual evaluation gives (-max / d0^2) = -inf and inf * 0 = NaN tangents
         // (critics/proxemics_cost_function.hpp:127,147) -> Ceres rejects the evaluation. Mirror it.
         gx = gy = __longlong_as_double(0x7ff8000000000000ll);
       }
       if (kRows) emit(2, live, people, r, gx, gy, 0.0, 0.0);
-      else {
-        r = people ? r : 0.0; gx = people ? gx : 0.0; gy = people ? gy : 0.0;
+      else {  // (a slot without people: pbest is still the largest double, exp gives r = 0 and with it gx = gy = 0)
         Axx = fma(gx, gx, Axx); Axy = fma(gx, gy, Axy); Ayy = fma(gy, gy, Ayy);
         bx = fma(gx, r, bx); by = fma(gy, r, by); cc = fma(r, r, cc);
       }
@@ -952,11 +1001,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   SMPC_STAMP2(c, 1);  // velocity, goal, 2 x distance
   // a5 obstacle
   {
-    const double inv_res = 1.0 / k.resolution;
+    const double inv_res = k.inv_resolution;
     // the same expressions as at the fetch (recomputed rather than kept in registers across the agent loop)
-    const double ob_ic = (X + 0.25 * c1 - cst[4]) / k.resolution, ob_ir = (Y + 0.25 * s1 - cst[5]) / k.resolution;
+    const double ob_ic = (X + 0.25 * c1 - cst[4]) * inv_res, ob_ir = (Y + 0.25 * s1 - cst[5]) * inv_res;
     double f, dfdr, dfdc;
-    if (wide_map) bicubic_eval(patch, ob_ir, ob_ic, f, dfdr, dfdc);
+    if (patch_interior) bicubic_eval<true>(patch, ob_ir, ob_ic, f, dfdr, dfdc);
+    else if (wide_map) bicubic_eval<false>(patch, ob_ir, ob_ic, f, dfdr, dfdc);
     else bicubic(c.map, k.size_x, k.size_y, ob_ir, ob_ic, f, dfdr, dfdc);  // maps narrower than one patch: byte by byte
     const double r = w.obstacle_w * f;
     const double gx = w.obstacle_w * dfdc * inv_res, gy = w.obstacle_w * dfdr * inv_res;

@@ -129,6 +129,9 @@ template <int NB> KernelFn pick_w(int W, bool eval) {
 }
 
 KernelFn pick(int nb, int W, bool eval) {
+#ifdef SMPC_ONLY_NB  // development builds: one instantiation only (seconds instead of a minute to compile)
+  return nb == SMPC_ONLY_NB ? pick_w<SMPC_ONLY_NB>(W, eval) : nullptr;
+#endif
   switch (nb) {
     case 1: return pick_w<1>(W, eval);
     case 2: return pick_w<2>(W, eval);
@@ -164,7 +167,7 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
   k->B = sb->B; k->T = sb->T; k->N = sb->N;
   k->CH = d.CH; k->bl = d.bl; k->nb = d.nb; k->P = d.P; k->nbounded = d.nbounded; k->nfeas = d.nfeas;
   k->size_x = sb->size_x; k->size_y = sb->size_y; k->costmap_shared = sb->costmap_shared;
-  k->dt = sb->dt; k->resolution = sb->resolution;
+  k->dt = sb->dt; k->resolution = sb->resolution; k->inv_resolution = 1.0 / sb->resolution;
   k->prm = h->prm;
   k->e_M = d.M;
   smpc::fill_math_table(&k->mt);

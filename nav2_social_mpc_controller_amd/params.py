@@ -140,6 +140,26 @@ class OptimizerParams:
             time_step=0.05, max_time=2.0)
 
     @staticmethod
+    def soc_work_obst_benchmark() -> "OptimizerParams":
+        """params/soc_work_obst_parameters_in_benchmark.yaml:104-136 as shipped (proxemics_weight absent -> code default
+        90; the benchmark's local costmap is 4 m x 4 m at 0.05 m = 80 x 80 cells, :143-149)."""
+        return OptimizerParams(
+            linear_solver_type="DENSE_SCHUR", param_tol=1e-9, fn_tol=1e-5, gradient_tol=1e-8, max_iterations=40,
+            control_horizon=18, parameter_block_length=6, current_path_weight=1.0, current_cmds_weight=0.5,
+            distance_weight=20.0, social_weight=120.0, velocity_weight=10.0, angle_weight=250.0,
+            agent_angle_weight=40.0, velocity_feasibility_weight=5.0, goal_align_weight=10.0, obstacle_weight=0.13,
+            time_step=0.05, max_time=1.5)
+
+    @staticmethod
+    def obst_only_benchmark() -> "OptimizerParams":
+        """params/obst_only_parameters_in_benchmark.yaml:104-136: the same file with social_weight 0 and
+        agent_angle_weight 0 (:129,132) — people are still handed to the optimiser, so the social-work and agent-angle
+        rows exist with zero weight and the proxemics row keeps its code default 90."""
+        return OptimizerParams.soc_work_obst_benchmark().replace(social_weight=0.0, agent_angle_weight=0.0)
+
+    BENCHMARK_COSTMAP_CELLS = 80  # local costmap of both benchmark files: width = height = 4 m, resolution 0.05 m
+
+    @staticmethod
     def from_yaml(path: str, plugin: str = "FollowPath") -> "OptimizerParams":
         import yaml
 

@@ -47,7 +47,8 @@ def load_golden(name):
     return prm, sc, exp
 
 
-GOLDEN_CASES = ["ref_n3_phantom", "cfg3_n8", "params_yaml_n3", "cfg1_nopeople_qr", "quirk_unbounded_last_block"]
+GOLDEN_CASES = ["ref_n3_phantom", "cfg3_n8", "params_yaml_n3", "cfg1_nopeople_qr", "quirk_unbounded_last_block",
+                "soc_work_obst_benchmark", "obst_only_benchmark"]
 
 
 def cmd_err(a, b):

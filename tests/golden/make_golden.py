@@ -34,6 +34,12 @@ CASES = {
     "cfg1_nopeople_qr": (OptimizerParams.params_yaml().replace(control_horizon=18, linear_solver_type="DENSE_QR"),
                          dict(B=2, N=3, map_cells=80, seed=14, people_present=False), 1),
     "quirk_unbounded_last_block": (readme.replace(time_step=0.1), dict(B=2, N=3, map_cells=80, seed=15), 1),
+    # the reference's shipped benchmark parameter sets (params/*_in_benchmark.yaml:104-149): 80 x 80 local costmap, three
+    # agents (people_to_status pads to 3); obst_only has people present with social_weight = agent_angle_weight = 0
+    "soc_work_obst_benchmark": (OptimizerParams.soc_work_obst_benchmark(),
+                                dict(B=4, N=3, n_valid=2, map_cells=OptimizerParams.BENCHMARK_COSTMAP_CELLS, seed=16), 1),
+    "obst_only_benchmark": (OptimizerParams.obst_only_benchmark(),
+                            dict(B=4, N=3, map_cells=OptimizerParams.BENCHMARK_COSTMAP_CELLS, seed=17), 1),
 }
 
 

@@ -56,6 +56,10 @@ EVAL_CASES = {
     "t32_first_one_slot_shape": (README.replace(max_time=1.70), dict(B=6, N=5, seed=115, map_cells=100)),
     "n32_last_two_slot_shape": (README, dict(B=6, N=32, seed=116, map_cells=120)),
     "t1_shortest_horizon": (README, dict(B=6, N=3, T=1, seed=117, map_cells=80)),
+    # the reference's shipped benchmark parameter sets (params/*_in_benchmark.yaml:104-149): 80 x 80 local costmap, three
+    # agents; obst_only: people present, social_weight = agent_angle_weight = 0 (rows exist, all zero)
+    "soc_work_obst_benchmark": (OptimizerParams.soc_work_obst_benchmark(), dict(B=64, N=3, n_valid=2, map_cells=80, seed=120)),
+    "obst_only_benchmark": (OptimizerParams.obst_only_benchmark(), dict(B=64, N=3, map_cells=80, seed=121)),
 }
 
 
@@ -124,6 +128,8 @@ SOLVE_CASES = {
     "t31_last_two_slot_shape": (README.replace(max_time=1.65), dict(B=48, N=5, seed=214, map_cells=100)),
     "t32_first_one_slot_shape": (README.replace(max_time=1.70), dict(B=48, N=5, seed=215, map_cells=100)),
     "n32_last_two_slot_shape": (README, dict(B=32, N=32, seed=216, map_cells=120, standing_fraction=0.0)),
+    "soc_work_obst_benchmark": (OptimizerParams.soc_work_obst_benchmark(), dict(B=256, N=3, n_valid=2, map_cells=80, seed=220)),
+    "obst_only_benchmark": (OptimizerParams.obst_only_benchmark(), dict(B=256, N=3, map_cells=80, seed=221)),
 }
 
 

@@ -52,6 +52,21 @@ def test_yaml_reader_handles_a_nav2_shaped_file(tmp_path):
     assert p.max_time == 1.5 and p.rollout_steps == 28
 
 
+def test_benchmark_presets_are_the_shipped_parameter_files():
+    """OptimizerParams.soc_work_obst_benchmark / obst_only_benchmark against what the YAML reader finds in the reference's
+    own params/*_in_benchmark.yaml:104-136 (read here, in the build container; the GPU box does not have the reference)."""
+    ref = "/root/reference/params"
+    a, b = OptimizerParams.soc_work_obst_benchmark(), OptimizerParams.obst_only_benchmark()
+    assert (a.social_weight, a.agent_angle_weight, a.obstacle_weight, a.proxemics_weight) == (120.0, 40.0, 0.13, 90.0)
+    assert (b.social_weight, b.agent_angle_weight, b.obstacle_weight, b.proxemics_weight) == (0.0, 0.0, 0.13, 90.0)
+    assert a.dims(a.rollout_steps) == (18, 6, 3, 6, 226, 3) and a.rollout_steps == 28
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present on this machine")
+    assert OptimizerParams.from_yaml(os.path.join(ref, "soc_work_obst_parameters_in_benchmark.yaml")) == a
+    assert OptimizerParams.from_yaml(os.path.join(ref, "obst_only_parameters_in_benchmark.yaml")) == b
+    assert OptimizerParams.from_yaml(os.path.join(ref, "params.yaml")) == OptimizerParams.params_yaml()
+
+
 def test_time_step_is_a_widened_float():
     p = OptimizerParams.readme()
     assert p.dt == float(np.float32(0.05)) and p.dt != 0.05
