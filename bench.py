@@ -42,18 +42,36 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL needs dmabuf IPC on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    line, _ = procs[0].communicate()
-    codes = [procs[0].returncode]
-    for pr in procs[1:]:
-        try:
-            codes.append(pr.wait(timeout=600 if codes[0] == 0 else 30))
-        except subprocess.TimeoutExpired:  # a rank that outlives a failed rank 0 would wait in a collective for ever
-            pr.kill()
-            codes.append(pr.wait())
+    # rank 0's stdout is read on a thread while every rank is polled: a rank that dies leaves the others waiting in a
+    # collective, so the first non-zero exit ends the run (the remaining ranks — exactly the PIDs started here — are
+    # terminated) and no line is printed
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
     if any(c != 0 for c in codes):
         sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
-        return next(c for c in codes if c != 0) or 1
-    sys.stdout.write(line)
+        return next(c for c in codes if c not in (0, None)) or 1
+    sys.stdout.write("".join(buf))
     sys.stdout.flush()
     return 0
 
@@ -241,8 +259,9 @@ def shape_record(prm, B, N, device, local_rank, reps=3, **scene_kw):
             "bytes_per_sweep": bytes_sweep, "failures": int((st == 2).sum())}
 
 
-def parity_sample(prm, scenes, got_cmds, n_sample, cores):
-    """The oracle (CPU restatement, checker) on the first n_sample scenes of this rank's shard."""
+def parity_sample(prm, scenes, out, n_sample, cores):
+    """The oracle (CPU restatement, checker) on the first n_sample scenes of this rank's shard. `out`: the result tensors
+    of the solve of those scenes."""
     import numpy as np
 
     from oracle import oracle_py as O
@@ -251,15 +270,25 @@ def parity_sample(prm, scenes, got_cmds, n_sample, cores):
     ref = O.solve(prm, sample, nthreads=cores)          # reference-literal oracle: also the timed CPU baseline
     cpu_s = time.perf_counter() - t1
     refz = O.solve(prm, sample, nthreads=cores, theta_zero_convention=True)   # checker (parity)
-    got = got_cmds[:n_sample]
+    got = out["cmds"].cpu().numpy()[:n_sample]
+    got_cost = out["final_cost"].cpu().numpy()[:n_sample]
     dcmd = np.abs(got - refz["cmds"]).reshape(n_sample, -1).max(axis=1)
     firm = refz["marginal_decisions"] == 0
     clean = (ref["sign_noise_events"] == 0) & (ref["marginal_decisions"] == 0)
     dlit = np.abs(got - ref["cmds"]).reshape(n_sample, -1).max(axis=1)
+    # every scene over the tolerance is listed with its cost gap: a scene that took another LM path must still end on an
+    # equally good optimum (relative gap of the final costs; negative = the device's optimum is the lower one)
+    over = np.where(dcmd > 1e-5)[0]
+    gap = (got_cost - refz["final_cost"]) / np.maximum(refz["final_cost"], 1e-300)
+    listed = [{"scene": int(i), "firm": bool(firm[i]), "abs_dcmd": float(dcmd[i]), "rel_cost_gap": float(gap[i]),
+               "device_iterations": int(out["iterations"][i].item()), "oracle_iterations": int(refz["iterations"][i])}
+              for i in over[np.argsort(-dcmd[over])][:16]]
     par = {"scenes": int(n_sample), "scenes_with_firm_decisions": int(firm.sum()),
            "max_abs_dcmd": float(dcmd[firm].max()), "median_abs_dcmd": float(np.median(dcmd)),
            "scenes_over_1e-5": int((dcmd[firm] > 1e-5).sum()),
            "scenes_over_1e-5_among_marginal": int((dcmd[~firm] > 1e-5).sum()),
+           "scenes_over_1e-5_listed": listed,
+           "worst_rel_cost_gap_over_1e-5": float(gap[over].max()) if len(over) else None,
            "checker": "CPU oracle (parity unpinned: restatement, not Ceres), theta:=0 convention for exactly equal velocities",
            "literal_oracle": {"scenes_without_sign_noise": int(clean.sum()),
                               "max_abs_dcmd_on_those": float(dlit[clean].max()) if clean.any() else None}}

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 3
+#define SMPC_ABI_VERSION 4
 #define SMPC_MAX_BLOCKS 10 /* nb <= 10  => P <= 20; every nb in 1..10 is instantiated */
 #define SMPC_MAX_LM_ITERATIONS 100000 /* smpc_create refuses a larger max_iterations: a persistent wave must reach its exit */
 #define SMPC_MAX_STEPS 63  /* T <= 63: one lane per pose of the rollout (T + 1 poses in a 64-lane wavefront) */
@@ -142,6 +142,17 @@ typedef struct smpc_scene_batch {
    * with a tail of late-started long scenes: 3.25 ms against 2.40 ms longest-first at the headline batch). NULL:
    * index order. */
   const int32_t* order; /* [B] */
+
+  /* Optional: the rollout steps of each scene, 1 <= T_scene[b] <= T (checked for host arrays; device arrays are clamped
+   * into that range by the kernel). The reference solves whatever horizon the tick produces — T = optim_velocities.size()
+   * after the pop_back (src/optimizer.cpp:237), one less than the poses format_to_optimize kept (:492-497) — so a robot
+   * whose trajectorized path ends before the batch's horizon (it is about to reach its goal) is solved with its own
+   * T_b, CH_b = min(control_horizon, T_b), bl_b = min(parameter_block_length, CH_b) (:248-249) and the block, bound and
+   * feasibility-row counts that follow from them. Every array keeps the batch's strides (T + 1 poses, P parameters): of
+   * path_pts / people the first T_b + 1 entries of scene b are read (its final point is path_pts[b][T_b]), of
+   * init_params the first P_b; results: params[P_b..P) = 0, cmds / path rows beyond T_b are written as zeros.
+   * NULL: every scene has T steps. */
+  const int32_t* T_scene; /* [B] */
 } smpc_scene_batch;
 
 #define SMPC_NO_TARGET 1e300 /* people_aux: AgentAngleCost is inactive at this step */

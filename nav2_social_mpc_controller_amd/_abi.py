@@ -6,7 +6,7 @@ Struct layouts must stay in lock-step with include/smpc.h (checked by tests/test
 """
 import ctypes as C
 
-SMPC_ABI_VERSION = 3
+SMPC_ABI_VERSION = 4
 SMPC_MAX_BLOCKS = 10
 
 # enum smpc_linear_solver (mirrors OptimizerParams::solver_types, reference optimizer.hpp:71-77)
@@ -77,6 +77,7 @@ class SmpcSceneBatch(C.Structure):
         ("people_records", C.c_void_p),
         ("people_aux", C.c_void_p),
         ("order", C.c_void_p),
+        ("T_scene", C.c_void_p),
     ]
 
 

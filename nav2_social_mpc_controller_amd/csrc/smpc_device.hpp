@@ -39,6 +39,7 @@ struct KParams {
   const double* goal_yaw;
   const double* people;
   const uint8_t* has_people;
+  const int32_t* T_scene;  // [B] rollout steps of each scene (<= T), or null: every scene has T (smpc_scene_batch.T_scene)
   const uint8_t* costmap;
   const double* costmap_origin;
   // solve outputs
@@ -91,6 +92,8 @@ struct LdsLayout {
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
   int inc;      // [4][T+1]   inclusive scans over j of cos, sin, j cos, j sin(theta_j) of the current sweep
   int cst;      // [8]        x0, y0, yaw0, goal_yaw, origin x, origin y, final point x, y
+  int hz;       // [4]        the scene's own horizon (kernels with per-scene T): ints T, CH, bl, last block, feasibility
+                //            rows, bounded blocks
   int lanec;    // [3][T]     per step: path point x, y (path_pts[t+1]) and agent-angle target (kNoTarget = none)
   int lm;       // LM vectors / matrices / scalars
   int gram;     // [(P+1)^2] Gram of the latest sweep (VALU back-end; the MFMA back-end uses the wave's result tile)
@@ -116,6 +119,7 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
     if (want > 6 * (T + 1)) o += want - 6 * (T + 1);
   }
   L.cst = o; o += 8;
+  L.hz = o; o += 4;
   L.lanec = o; o += 3 * T;
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;  // Hs, six vectors, scalars: what lives from trip to trip
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
@@ -568,13 +572,58 @@ __device__ inline void stage_people(KParamsK kp, int scene, int sl, double* ag, 
   }
 }
 
+// The horizon of the slot's scene: rollout steps T, control horizon CH = min(control_horizon, T), block length
+// bl = min(parameter_block_length, CH), index of the last parameter block, feasibility rows and bounded blocks
+// (src/optimizer.cpp:248-249, 364, 373). kVT = false: one T per batch, everything is a launch constant (scalar
+// registers) and the last block is NB - 1. kVT = true (smpc_scene_batch.T_scene): per scene, kept in LDS by load_scene();
+// a scene with fewer blocks than the batch's NB keeps its surplus parameters at exactly zero — their Jacobian columns
+// are zero, the damped system is block diagonal and every sum gains exact zeros, so the iterates of the real
+// parameters are those of the smaller problem bit for bit.
+struct Horizon { int T, CH, bl, blast, nfeas, nbounded; };
+
+template <int NB, bool kVT> __device__ inline Horizon get_horizon(const Ctx& c) {
+  Horizon h;
+  if (!kVT) {
+    const auto& k = *c.kp;
+    h.T = k.T; h.CH = k.CH; h.bl = k.bl; h.blast = NB - 1; h.nfeas = k.nfeas; h.nbounded = k.nbounded;
+  } else {
+    const int* z = reinterpret_cast<const int*>(c.lds + c.L.hz);
+    h.T = z[0]; h.CH = z[1]; h.bl = z[2]; h.blast = z[3]; h.nfeas = z[4]; h.nbounded = z[5];
+  }
+  return h;
+}
+
+// the block driving step sl: min(sl, CH - 1) / bl, as a count of block starts at or before it (no division)
+template <int NB> __device__ inline int block_of_step(int sl, const Horizon& h) {
+  const int t = min(sl, h.CH - 1);
+  int b = 0;
+#pragma unroll
+  for (int q = 1; q < NB; ++q) b += (t >= q * h.bl) ? 1 : 0;
+  return b;
+}
+
+// one past the last step block b drives: the next block's start, the horizon for the last block, nothing beyond it
+__device__ inline int block_end(int b, const Horizon& h) {
+  return b < h.blast ? (b + 1) * h.bl : (b == h.blast ? h.T : b * h.bl);
+}
+
 // Load the slot's scene constants and the per-step side data of its staged people block (valid masks, agent-angle
 // tags) into LDS; the records themselves stay in global memory (c.ag). Executed by all W lanes of the slot (other
 // slots may be masked off).
-template <int W>
+template <int W, bool kVT = false>
 __device__ inline void load_scene(Ctx& c, int scene) {
   const auto& k = *c.kp;
   const int T = k.T, N = k.N, sl = c.sl;
+  int Th = T;  // the scene's own horizon
+  if (kVT) {
+    if (k.T_scene) Th = min(max(k.T_scene[scene], 1), T);
+    const int CH = min(k.prm.control_horizon, Th);
+    const int bl = max(min(k.prm.parameter_block_length, CH), 1);
+    int* z = reinterpret_cast<int*>(c.lds + c.L.hz);
+    z[0] = Th; z[1] = CH; z[2] = bl; z[3] = (CH - 1) / bl;
+    z[4] = max(min(CH / bl, Th) - 1, 0);  // src/optimizer.cpp:364
+    z[5] = CH / bl;                       // :373
+  }
   const size_t s = scene;
   c.scene = scene;
   c.has_people = (N > 0) && (k.has_people ? k.has_people[s] != 0 : true);
@@ -588,8 +637,8 @@ __device__ inline void load_scene(Ctx& c, int scene) {
   cst[3] = k.goal_yaw[s];
   cst[4] = k.costmap_origin[k.costmap_shared ? 0 : 2 * s];
   cst[5] = k.costmap_origin[k.costmap_shared ? 1 : 2 * s + 1];
-  cst[6] = path_pts[2 * T];
-  cst[7] = path_pts[2 * T + 1];
+  cst[6] = path_pts[2 * Th];  // final trajectorized point (src/optimizer.cpp:234-235)
+  cst[7] = path_pts[2 * Th + 1];
   double* lanec = c.lds + c.L.lanec;
   if (sl < T) {
     double aa_target = kNoTarget;
@@ -614,18 +663,19 @@ __device__ inline void load_scene(Ctx& c, int scene) {
 // kRows = true: the stand-alone K1 sweep; rows go to HBM, and of the Gram only its last column (J^T r and r^T r: the
 // gradient and the cost smpc_eval_batch reports) is accumulated, on the VALU — c.wave_lds is then the row staging
 // area of the critic-major store path (2 x T x P doubles per slot).
-template <int NB, int W, bool kRows>
+template <int NB, int W, bool kRows, bool kVT = false>
 __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J) {
   constexpr int P = 2 * NB;
   const auto& k = *c.kp;
-  const int T = k.T, N = k.N, CH = k.CH, bl = k.bl, sl = c.sl;
+  const int T = k.T, N = k.N, sl = c.sl;  // T: the batch's T = the stride of every per-step array
+  const Horizon hz = get_horizon<NB, kVT>(c);
+  const int Th = hz.T, CH = hz.CH, bl = hz.bl;  // Th: the scene's own rollout steps (== T unless kVT)
   const double dt = k.dt;
   double* cs_ = c.lds + c.L.cs;
   double* sn_ = cs_ + (T + 1);
   const double* cst = c.lds + c.L.cst;
-  const int blast = (CH - 1) / bl;
-  const int tl = min(sl, T - 1);
-  const int myb = (sl < CH) ? sl / bl : blast;  // block driving step sl
+  const int tl = min(sl, Th - 1);
+  const int myb = block_of_step<NB>(sl, hz);  // block driving step sl
   const double vb = xp[2 * myb], wb = xp[2 * myb + 1];
 
   // staged people records of this lane's step: agent a at agr[a * T]; the first two are requested now, so that their
@@ -644,7 +694,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int start = b * bl;
-    const int len = ((b == NB - 1) ? T : (b + 1) * bl) - start;
+    const int len = block_end(b, hz) - start;
     const int cnt = min(max(sl - start, 0), len);  // steps j < sl that block b drives
     th = fma(xp[2 * b + 1] * dt, (double)cnt, th);
   }
@@ -677,13 +727,13 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   double X = cst[0], Y = cst[1];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int end = (b == NB - 1) ? T : (b + 1) * bl;
+    const int end = block_end(b, hz);
     const int idx = (b < myb) ? end - 1 : tl;   // a finished block: its last step; the lane's own block: the lane
     const double m = (b <= myb) ? 1.0 : 0.0;
     const double vdt = xp[2 * b] * dt * m;
     X = fma(vdt, scan_[idx], X); Y = fma(vdt, scan_[(T + 1) + idx], Y);
   }
-  const int t1 = min(sl + 1, T);
+  const int t1 = min(sl + 1, Th);
   const double c1 = cs_[t1], s1 = sn_[t1];  // heading of the residual's pose
   // a5 obstacle: the costmap patch under the front point is requested now and used after the agent loop
   // cell coordinates of the front point: (front - origin) / resolution (critics/obstacle_cost_function.hpp:154-158) as a
@@ -826,7 +876,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int start = b * bl;
-      const int end = (b == NB - 1) ? T : (b + 1) * bl;
+      const int end = block_end(b, hz);
       const int idx = (b < myb) ? end - 1 : tl;
       const double m = (b <= myb) ? 1.0 : 0.0;
       const double aC = m * scan_[idx], aS = m * scan_[(T + 1) + idx];
@@ -860,10 +910,10 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   //               same pipe: measured slower than plain VALU accumulation).
   constexpr int Q = P + 1;
   const auto& w = k.prm;
-  const bool lane_live = sl < T;
+  const bool lane_live = sl < Th;
   const bool people = c.has_people;
   const int rows_per_step = people ? 8 : 5;
-  const int row_base = rows_per_step * sl + min(max(sl - 1, 0), k.nfeas);
+  const int row_base = rows_per_step * sl + min(max(sl - 1, 0), hz.nfeas);
   double gcol[Q];      // kRows: last column of the Gram only
   double Axx = 0.0, Axy = 0.0, Axt = 0.0, Axv = 0.0, Ayy = 0.0, Ayt = 0.0, Ayv = 0.0, Att = 0.0, Atv = 0.0, Avv = 0.0;
   double bx = 0.0, by = 0.0, bt = 0.0, bv = 0.0, cc = 0.0;
@@ -892,7 +942,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       // consecutive 16-byte pieces (lane-strided 48-byte rows touch 64 different lines per instruction and leave
       // partially written lines behind: measured 1.49 x write amplification in round 1).
       double* blk = stage + (local & 1) * (T * P);
-      if (lane_live && slot_on) {
+      if (sl < T && slot_on) {  // every row of the block, the all-zero rows of steps beyond the scene's horizon included
 #pragma unroll
         for (int q = 0; q < P; q += 2) {
           v2d pr = {live ? row[q] : 0.0, live ? row[q + 1] : 0.0};
@@ -905,7 +955,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         const v2d* src = reinterpret_cast<const v2d*>(blk);
         for (int i = sl; i < T * NB; i += W) dst[i] = src[i];
       }
-      if (out_r && lane_live && slot_on) out_r[local * T + sl] = r;
+      if (out_r && sl < T && slot_on) out_r[local * T + sl] = live ? r : 0.0;
       // no second fence: the next critic writes the other block, and the one after that comes behind this
       // critic's reads in program order with a fence in between
     } else if (live) {
@@ -1026,7 +1076,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
   if (kRows) {
     // a9 velocity feasibility between blocks sl and sl-1 (src/optimizer.cpp:364-370); the row follows step sl
     if (k.nfeas > 0) {
-      const bool live = lane_live && sl >= 1 && sl <= k.nfeas;
+      const bool live = lane_live && sl >= 1 && sl <= hz.nfeas;
       double row[P];
 #pragma unroll
       for (int q = 0; q < P; ++q) row[q] = 0.0;
@@ -1068,7 +1118,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     // a9 velocity feasibility rows (src/optimizer.cpp:364-370): row q (between blocks q and q-1, 1 <= q <= nfeas) has
     // four non-zero entries; the rows go to LDS as they are and their outer products are added after the lane sum.
     double* frow = c.wave_lds + c.slot * ((NB > 1 ? NB - 1 : 1) * Q);
-    if (sl >= 1 && sl <= k.nfeas) {
+    if (sl >= 1 && sl <= hz.nfeas) {
       const double lin = xp[2 * sl] - xp[2 * sl - 2], ang = xp[2 * sl + 1] - xp[2 * sl - 1];
       const double wf = w.velocity_feasibility_w;
       double* fr = frow + (sl - 1) * Q;
@@ -1105,7 +1155,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
         for (int cb = 1; cb < Q; ++cb) if (cb > col_lo && cb <= col_hi) bcol = (pidx >= cb * (cb + 1) / 2) ? cb : bcol;
         const int arow = pidx - bcol * (bcol + 1) / 2;
-        for (int q = 0; q < k.nfeas; ++q) tot = fma(frow[q * Q + arow], frow[q * Q + bcol], tot);
+        for (int q = 0; q < hz.nfeas; ++q) tot = fma(frow[q * Q + arow], frow[q * Q + bcol], tot);
         gt[arow * Q + bcol] = tot;
         gt[bcol * Q + arow] = tot;
       }

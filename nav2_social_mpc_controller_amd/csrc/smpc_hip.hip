@@ -123,26 +123,32 @@ namespace {
 
 using KernelFn = void (*)(const smpc::KParams);
 
-template <int NB> KernelFn pick_w(int W, bool eval) {
+// vt: the batch carries a horizon per scene (smpc_scene_batch.T_scene): the instantiation that reads T, CH, bl of each
+// scene from LDS instead of taking them as launch constants
+template <int NB> KernelFn pick_w(int W, bool eval, bool vt) {
+  if (vt) {
+    if (W == 32) return eval ? smpc::smpc_eval_kernel<NB, 32, true> : smpc::smpc_solve_kernel<NB, 32, true>;
+    return eval ? smpc::smpc_eval_kernel<NB, 64, true> : smpc::smpc_solve_kernel<NB, 64, true>;
+  }
   if (W == 32) return eval ? smpc::smpc_eval_kernel<NB, 32> : smpc::smpc_solve_kernel<NB, 32>;
   return eval ? smpc::smpc_eval_kernel<NB, 64> : smpc::smpc_solve_kernel<NB, 64>;
 }
 
-KernelFn pick(int nb, int W, bool eval) {
+KernelFn pick(int nb, int W, bool eval, bool vt = false) {
 #ifdef SMPC_ONLY_NB  // development builds: one instantiation only (seconds instead of a minute to compile)
-  return nb == SMPC_ONLY_NB ? pick_w<SMPC_ONLY_NB>(W, eval) : nullptr;
+  return nb == SMPC_ONLY_NB ? pick_w<SMPC_ONLY_NB>(W, eval, vt) : nullptr;
 #endif
   switch (nb) {
-    case 1: return pick_w<1>(W, eval);
-    case 2: return pick_w<2>(W, eval);
-    case 3: return pick_w<3>(W, eval);
-    case 4: return pick_w<4>(W, eval);
-    case 5: return pick_w<5>(W, eval);
-    case 6: return pick_w<6>(W, eval);
-    case 7: return pick_w<7>(W, eval);
-    case 8: return pick_w<8>(W, eval);
-    case 9: return pick_w<9>(W, eval);
-    case 10: return pick_w<10>(W, eval);
+    case 1: return pick_w<1>(W, eval, vt);
+    case 2: return pick_w<2>(W, eval, vt);
+    case 3: return pick_w<3>(W, eval, vt);
+    case 4: return pick_w<4>(W, eval, vt);
+    case 5: return pick_w<5>(W, eval, vt);
+    case 6: return pick_w<6>(W, eval, vt);
+    case 7: return pick_w<7>(W, eval, vt);
+    case 8: return pick_w<8>(W, eval, vt);
+    case 9: return pick_w<9>(W, eval, vt);
+    case 10: return pick_w<10>(W, eval, vt);
     default: return nullptr;
   }
 }
@@ -273,7 +279,7 @@ int bind_people(smpc_handle* h, const smpc_scene_batch* sb, smpc::KParams& k, St
 int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   const int W = smpc::slot_width(k.T, k.N);
   const int S = smpc::kWave / W;
-  KernelFn fn = pick(k.nb, W, eval);
+  KernelFn fn = pick(k.nb, W, eval, k.T_scene != nullptr);
   const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve);
   // behind the slot blocks: the MFMA row / result tiles (solve) or the two row staging blocks per slot (K1)
   const size_t extra = eval ? (size_t)S * 2 * k.T * k.P : (size_t)smpc::wave_extra_doubles(k.P, W);
@@ -347,7 +353,13 @@ int bind_inputs(smpc_handle* h, const smpc_scene_batch* sb, const Dims& d, smpc:
   if (sb->on_device) {
     k->pose0 = sb->pose0; k->init_params = sb->init_params; k->path_pts = sb->path_pts; k->goal_yaw = sb->goal_yaw;
     k->people = sb->people; k->has_people = sb->has_people; k->costmap = sb->costmap; k->costmap_origin = sb->costmap_origin;
+    k->T_scene = sb->T_scene;  // device array: trusted, the kernel clamps every entry into 1..T
     return SMPC_OK;
+  }
+  if (sb->T_scene) {
+    for (size_t i = 0; i < B; ++i)
+      if (sb->T_scene[i] < 1 || sb->T_scene[i] > sb->T) { set_error("T_scene entries must lie in 1..T"); return SMPC_ERR_INVALID_ARG; }
+    SMPC_TRY(st->up(sb->T_scene, B, &k->T_scene, h->stream));
   }
   SMPC_TRY(st->up(sb->pose0, B * 3, &k->pose0, h->stream));
   SMPC_TRY(st->up(sb->init_params, B * d.P, &k->init_params, h->stream));

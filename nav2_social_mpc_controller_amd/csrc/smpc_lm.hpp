@@ -439,15 +439,17 @@ struct LmRegs {  // slot-uniform integers / flags kept in registers
   bool step_successful, at_least_one, prev_vv, prev_gv, cur_vv, cur_gv, first_vv;
 };
 
+// waves per SIMD the solve kernel's register allocation must allow: three up to three parameter blocks (the headline
+// shapes sit at 160-168 registers; stated so that an edit cannot silently cost the third wave), two beyond
 #ifndef SMPC_SOLVE_MIN_WAVES
-#define SMPC_SOLVE_MIN_WAVES 2   // waves per SIMD the solve kernel's register allocation must allow
+#define SMPC_SOLVE_MIN_WAVES(NB) ((NB) <= 3 ? 3 : 2)
 #endif
 // The LM vectors and matrices of a slot are spread over its lanes: lane q < P owns parameter q (its entry of x, of the
 // trial point, of the step, row q of the scaled Gram and of its Cholesky factor). One instruction then updates all P
 // entries; sums over the parameters go through a few LDS words in index order (the same order a serial loop would
 // add them in). Nothing P x P lives in registers, so the P = 8..12 instantiations do not spill.
-template <int NB, int W>
-__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(const KParams) {
+template <int NB, int W, bool kVT = false>
+__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kernel(const KParams) {
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
@@ -459,7 +461,6 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
   c.ag = k.people_rec;
   const auto& prm = k.prm;
   const int T = k.T;
-  const int blast = (k.CH - 1) / k.bl;
   // Everything below is derived from the lane index. It is re-derived at the top of every trip and again behind the
   // sweep from a copy of the lane index the compiler cannot see through (an empty asm): otherwise these ~20 addresses
   // and flags are computed once in the prologue, stay live through the whole kernel — the sweep runs at the VGPR limit —
@@ -560,16 +561,18 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
       }
       scene = __shfl(scene, slot * W, 64);
       if (scene < k.B) {
-        load_scene<W>(c, scene);
+        load_scene<W, kVT>(c, scene);
         ever_loaded = true;
+        wave_lds_fence();
+        const Horizon hz0 = get_horizon<NB, kVT>(c);
         double v = 0.0;
-        if (act) {
-          const bool bnd = (q >> 1) < k.nbounded;
+        if (act && (q >> 1) <= hz0.blast) {  // a scene with fewer blocks than NB keeps the surplus parameters at zero
+          const bool bnd = (q >> 1) < hz0.nbounded;
           const double lo0 = bnd ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
           const double hi0 = bnd ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
           v = clampd(k.init_params[(size_t)scene * P + q] + 0.0, lo0, hi0);  // Plus(x, 0): project the start point (A.4)
-          xc[q] = v; xt[q] = v;
         }
+        if (act) { xc[q] = v; xt[q] = v; }
         double xn, u0, u1;
         reduce3(0, v * v, 0.0, 0.0, xn, u0, u1);
         sv[S_XNORM] = fast_sqrt(xn);
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         R.step_successful = true; R.at_least_one = false;
       } else {
         if (!ever_loaded) {  // keep the sweep's memory accesses in bounds for a slot that never got a scene
-          load_scene<W>(c, 0);
+          load_scene<W, kVT>(c, 0);
           ever_loaded = true;
           if (act) xt[q] = 0.0;
         }
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
     park();
-    sweep<NB, W, false>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    sweep<NB, W, false, kVT>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
     {
       int lane_t = lane;
       asm volatile("" : "+v"(lane_t));
@@ -601,8 +604,9 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
     GH.base = c.lds + c.L.gram;
     GH.ld = P + 1;
     unpark();
+    const Horizon hz = get_horizon<NB, kVT>(c);
     // bounds of parameter q (src/optimizer.cpp:373-379: blocks 0..CH/bl-1 are bounded)
-    const bool bounded = act && (q >> 1) < k.nbounded;
+    const bool bounded = act && (q >> 1) < hz.nbounded;
     const double lo_q = bounded ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
     const double hi_q = bounded ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
     // usable iff every residual and Jacobian entry was finite: a non-finite one makes its diagonal Gram entry non-finite
@@ -838,12 +842,15 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         if (k.o_final_cost) k.o_final_cost[s] = sv[S_COST];
       }
       if (k.o_params && c.sl < P) k.o_params[s * P + c.sl] = xc[c.sl];
-      // saving_velocities[i], i = 0..T: block i/bl for i < CH, else the last block (src/optimizer.cpp:390-411)
+      // saving_velocities[i], i = 0..T: block i/bl for i < CH, else the last block (src/optimizer.cpp:390-411); a scene
+      // with a horizon of its own has Th + 1 entries, the rows behind them are written as zeros
+      const int Th = hz.T;
       if (k.o_cmds) {
         for (int i = c.sl; i <= T; i += W) {
-          const int b = (i < k.CH) ? i / k.bl : blast;
-          k.o_cmds[(s * (T + 1) + i) * 2] = xc[2 * b];
-          k.o_cmds[(s * (T + 1) + i) * 2 + 1] = xc[2 * b + 1];
+          const int b = block_of_step<NB>(i, hz);
+          const bool in = i <= Th;
+          k.o_cmds[(s * (T + 1) + i) * 2] = in ? xc[2 * b] : 0.0;
+          k.o_cmds[(s * (T + 1) + i) * 2 + 1] = in ? xc[2 * b + 1] : 0.0;
         }
       }
       if (k.o_path) {
@@ -855,15 +862,15 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
         double yaw = wrap_angle(cst[2]);
         double my_yaw_in = yaw, my_yaw_out = yaw;
         for (int i = 0; i <= T; ++i) {
-          const int b = (i < k.CH) ? i / k.bl : blast;
+          const int b = block_of_step<NB>(i, hz);
           const double nyaw = wrap_angle(yaw + xc[2 * b + 1] * k.dt);
           if (i == c.sl) { my_yaw_in = yaw; my_yaw_out = nyaw; }
           yaw = nyaw;
         }
-        const int bi = (c.sl < k.CH) ? c.sl / k.bl : blast;
+        const int bi = block_of_step<NB>(c.sl, hz);
         double sn, cs;
         sincos(my_yaw_in, &sn, &cs);
-        const double v = (c.sl <= T) ? xc[2 * min(bi, NB - 1)] : 0.0;
+        const double v = (c.sl <= T) ? xc[2 * bi] : 0.0;
         const double tx = v * cs * k.dt, ty = v * sn * k.dt;
         double px = cst[0], py = cst[1], mx = 0.0, my = 0.0;
         for (int i = 0; i <= T; ++i) {
@@ -872,8 +879,9 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
           if (i == c.sl) { mx = px; my = py; }
         }
         if (c.sl <= T) {
+          const bool in = c.sl <= Th;
           double* o = k.o_path + (s * (T + 1) + c.sl) * 3;
-          o[0] = mx; o[1] = my; o[2] = my_yaw_out;
+          o[0] = in ? mx : 0.0; o[1] = in ? my : 0.0; o[2] = in ? my_yaw_out : 0.0;
         }
       }
       R.phase = PH_FETCH;
@@ -888,11 +896,14 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES) void smpc_solve_kernel(co
 }
 
 // K1 stand-alone: one sweep per scene at given parameters, rows written to HBM (parity checks, roofline runs).
+// Up to three parameter blocks the sweep fits the 168 registers that three waves per SIMD allow (the headline shapes;
+// K1 is a latency-bound streaming kernel, the third wave is worth 20 % of its time); beyond that the row buffers grow
+// with P and the allocator is left alone.
 #ifndef SMPC_EVAL_MIN_WAVES
-#define SMPC_EVAL_MIN_WAVES 1
+#define SMPC_EVAL_MIN_WAVES(NB) ((NB) <= 3 ? 3 : 1)
 #endif
-template <int NB, int W>
-__global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(const KParams) {
+template <int NB, int W, bool kVT = false>
+__global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES(NB)) void smpc_eval_kernel(const KParams) {
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
@@ -915,19 +926,31 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES) void smpc_eval_kernel(cons
   const int scene_raw = blockIdx.x * S + slot;
   const bool live = scene_raw < k.B;
   const int scene = live ? scene_raw : k.B - 1;
-  load_scene<W>(c, scene);
+  load_scene<W, kVT>(c, scene);
+  wave_lds_fence();
   SMPC_STAMP(c, 0);
   const size_t s = scene;
   double* out_r = (live && k.e_residuals) ? k.e_residuals + s * k.e_M : nullptr;
   double* out_J = (live && k.e_jacobian) ? k.e_jacobian + s * (size_t)k.e_M * P : nullptr;
-  if (!c.has_people) {  // rows a scene without people does not have stay zero
-    const int M5 = 5 * k.T + k.nfeas;
-    for (int i = M5 + c.sl; i < k.e_M; i += W) {
+  const Horizon hz = get_horizon<NB, kVT>(c);
+  if (!c.has_people || kVT) {
+    // rows the scene does not have stay zero: the people rows of a scene without people, and — reference row order —
+    // everything behind the 8 (or 5) Th + n_feasibility rows of a scene with a horizon of its own (in the critic-major
+    // order the sweep itself writes the zero rows of every critic block it visits)
+    const int Mb = (c.has_people ? 8 : 5) * (k.e_row_order == 1 ? k.T : hz.T) + (k.e_row_order == 1 ? k.nfeas : hz.nfeas);
+    for (int i = Mb + c.sl; i < k.e_M; i += W) {
       if (out_r) out_r[i] = 0.0;
       if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)i * P + q] = 0.0;
     }
+    if (kVT && k.e_row_order == 1) {  // critic-major: the feasibility rows the scene does not have
+      const int base = (c.has_people ? 8 : 5) * k.T;
+      for (int i = hz.nfeas + c.sl; i < k.nfeas; i += W) {
+        if (out_r) out_r[base + i] = 0.0;
+        if (out_J) for (int q = 0; q < P; ++q) out_J[(size_t)(base + i) * P + q] = 0.0;
+      }
+    }
   }
-  const GramView G = sweep<NB, W, true>(c, k.e_x + s * P, out_r, out_J);
+  const GramView G = sweep<NB, W, true, kVT>(c, k.e_x + s * P, out_r, out_J);
   if (live && c.sl == 0 && k.e_cost) k.e_cost[s] = 0.5 * G(P, P);
   if (live && k.e_gradient && c.sl < P) k.e_gradient[s * P + c.sl] = G(c.sl, P);
 #ifdef SMPC_STAMPS

@@ -49,6 +49,9 @@ class SceneBatch:
     costmap_origin: np.ndarray  # [B or 1,2]
     resolution: float
     costmap_shared: bool = False
+    # optional horizon of each scene, 1 <= T_scene[b] <= T (smpc_scene_batch.T_scene): of path_pts / people the first
+    # T_scene[b] + 1 rows of scene b count, of init_params the first P_b entries; None: every scene has T steps
+    T_scene: Optional[np.ndarray] = None
 
     @property
     def B(self) -> int:
@@ -76,6 +79,8 @@ class SceneBatch:
         for a in (self.pose0, self.init_params, self.path_pts, self.goal_yaw, self.people, self.has_people,
                   self.costmap, self.costmap_origin):
             assert a.flags["C_CONTIGUOUS"]
+        if self.T_scene is not None:
+            assert self.T_scene.shape == (B,) and self.T_scene.dtype == np.int32 and self.T_scene.flags["C_CONTIGUOUS"]
 
     def to_c(self) -> SmpcSceneBatch:
         """C view over the host arrays (arrays stay owned by this object)."""
@@ -93,6 +98,8 @@ class SceneBatch:
         sb.size_x, sb.size_y = self.size_x, self.size_y
         sb.costmap_origin = self.costmap_origin.ctypes.data
         sb.resolution = self.resolution
+        if self.T_scene is not None:
+            sb.T_scene = self.T_scene.ctypes.data
         return sb
 
     def to_device(self, device="cuda:0"):
@@ -101,6 +108,8 @@ class SceneBatch:
 
         t = {k: torch.from_numpy(getattr(self, k)).to(device) for k in
              ("pose0", "init_params", "path_pts", "goal_yaw", "people", "has_people", "costmap", "costmap_origin")}
+        if self.T_scene is not None:
+            t["T_scene"] = torch.from_numpy(self.T_scene).to(device)
         sb = SmpcSceneBatch()
         sb.B, sb.T, sb.N, sb.on_device = self.B, self.T, self.N, 1
         sb.dt = self.dt
@@ -118,7 +127,27 @@ class SceneBatch:
         return SceneBatch(self.T, self.N, self.dt, np.ascontiguousarray(self.pose0[idx]),
                           np.ascontiguousarray(self.init_params[idx]), np.ascontiguousarray(self.path_pts[idx]),
                           np.ascontiguousarray(self.goal_yaw[idx]), np.ascontiguousarray(self.people[idx]),
-                          np.ascontiguousarray(self.has_people[idx]), cm, co, self.resolution, self.costmap_shared)
+                          np.ascontiguousarray(self.has_people[idx]), cm, co, self.resolution, self.costmap_shared,
+                          None if self.T_scene is None else np.ascontiguousarray(self.T_scene[idx]))
+
+    def with_horizons(self, T_scene) -> "SceneBatch":
+        """The same scenes with a horizon per scene: scene b keeps its first T_scene[b] + 1 poses / people rows; its goal
+        heading becomes the heading the path has at its own last pose (scenes built by make_scenes: the reference path
+        is an arc, so that is the heading after T_scene[b] steps)."""
+        T_scene = np.ascontiguousarray(T_scene, np.int32)
+        assert T_scene.shape == (self.B,) and T_scene.min() >= 1 and T_scene.max() <= self.T
+        out = self.select(np.arange(self.B))
+        out.T_scene = T_scene
+        return out
+
+    def cut(self, idx, Tb: int, P_b: int) -> "SceneBatch":
+        """Scenes idx as a batch whose T is Tb: what a caller with exactly these horizons would hand over (arrays
+        truncated to Tb + 1 rows and P_b parameters)."""
+        sub = self.select(idx)
+        return SceneBatch(Tb, self.N, self.dt, sub.pose0, np.ascontiguousarray(sub.init_params[:, :P_b]),
+                          np.ascontiguousarray(sub.path_pts[:, :Tb + 1]), sub.goal_yaw,
+                          np.ascontiguousarray(sub.people[:, :Tb + 1]), sub.has_people, sub.costmap, sub.costmap_origin,
+                          self.resolution, self.costmap_shared)
 
     def save(self, path: str):
         np.savez_compressed(path, T=self.T, N=self.N, dt=self.dt, pose0=self.pose0, init_params=self.init_params,

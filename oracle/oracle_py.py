@@ -56,9 +56,30 @@ def solve(params, scenes, nthreads=1, theta_zero_convention=False):
         set_theta_zero_convention(False)
 
 
+def _by_horizon(params, scenes, fn, shapes):
+    """Scenes with horizons of their own (SceneBatch.T_scene): every group of equal T_b is handed to the oracle as the
+    batch a caller with exactly that horizon would build (arrays cut to T_b + 1 rows / P_b parameters), and the results
+    are laid out with the full batch's strides, zeros where a scene has nothing — the layout include/smpc.h documents."""
+    B = scenes.B
+    out = None
+    for Tb in sorted(set(int(t) for t in scenes.T_scene)):
+        idx = np.where(scenes.T_scene == Tb)[0]
+        P_b = params.dims(Tb, True)[3]
+        sub = fn(scenes.cut(idx, Tb, P_b), Tb, idx)
+        if out is None:
+            out = {k: np.zeros((B,) + shapes[k], v.dtype) if k in shapes else np.zeros((B,) + v.shape[1:], v.dtype)
+                   for k, v in sub.items()}
+        for k, v in sub.items():
+            out[k][(idx,) + tuple(slice(0, n) for n in v.shape[1:])] = v
+    return out
+
+
 def _solve(params, scenes, nthreads=1):
     CH, bl, nb, P, M, _ = params.dims(scenes.T, True)
     B, T = scenes.B, scenes.T
+    if getattr(scenes, "T_scene", None) is not None:
+        return _by_horizon(params, scenes, lambda sub, Tb, idx: _solve(params, sub, nthreads),
+                           {"params": (P,), "cmds": (T + 1, 2), "path": (T + 1, 3)})
     out = {
         "params": np.zeros((B, P)), "cmds": np.zeros((B, T + 1, 2)), "path": np.zeros((B, T + 1, 3)),
         "status": np.zeros(B, np.int32), "reason": np.zeros(B, np.int32), "iterations": np.zeros(B, np.int32),
@@ -88,6 +109,10 @@ def evaluate(params, scenes, x, jacobian=True):
     B = scenes.B
     x = np.ascontiguousarray(x, dtype=np.float64)
     assert x.shape == (B, P)
+    if getattr(scenes, "T_scene", None) is not None:  # reference row order, rows / columns a scene does not have are zero
+        return _by_horizon(params, scenes,
+                           lambda sub, Tb, idx: evaluate(params, sub, x[idx][:, :params.dims(Tb, True)[3]], jacobian),
+                           {"residuals": (M,), "jacobian": (M, P), "gradient": (P,)})
     out = {"residuals": np.zeros((B, M)), "cost": np.zeros(B)}
     if jacobian:
         out["jacobian"] = np.zeros((B, M, P))

@@ -1,0 +1,161 @@
+"""Per-scene horizon (`smpc_scene_batch.T_scene`, `-m gpu`): the reference solves whatever T the tick produces
+(T = optim_velocities.size() after the pop_back, src/optimizer.cpp:237; CH / bl clamped to it, :248-249), so a batch may
+hold robots with different horizons. Checker: the CPU oracle run per group of equal T_b on the arrays a caller with
+exactly that horizon would hand over (oracle/oracle_py.py: _by_horizon)."""
+import numpy as np
+import pytest
+
+from conftest import cmd_err, well_conditioned
+from nav2_social_mpc_controller_amd.params import OptimizerParams
+from nav2_social_mpc_controller_amd.scenes import make_scenes
+
+pytestmark = pytest.mark.gpu
+
+README = OptimizerParams.readme()
+CMD_TOL = 1e-5
+JAC_RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def Solver():
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    return BatchSolver
+
+
+def horizons(B, T, seed):
+    """every T_b of 1..T at least once when B allows, the rest random"""
+    g = np.random.default_rng(seed)
+    Ts = np.concatenate([np.arange(1, T + 1), g.integers(1, T + 1, size=max(0, B - T))])[:B]
+    g.shuffle(Ts)
+    return Ts.astype(np.int32)
+
+
+CASES = {
+    "readme_n3": (README, dict(B=96, N=3, n_valid=2, map_cells=80, seed=401)),
+    "readme_n8": (README, dict(B=96, N=8, seed=402)),
+    "params_yaml_n3_w64": (OptimizerParams.params_yaml(), dict(B=96, N=3, seed=403)),
+    "five_blocks": (README.replace(parameter_block_length=4), dict(B=64, N=4, seed=404)),
+    "bl_not_dividing": (README.replace(time_step=0.1), dict(B=48, N=3, seed=405)),
+    "no_people": (README, dict(B=48, N=3, seed=406, people_present=False)),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_k1_rows_with_a_horizon_per_scene(Solver, oracle, name):
+    prm, kw = CASES[name]
+    sc = make_scenes(prm, **kw)
+    sv = sc.with_horizons(horizons(sc.B, sc.T, 7))
+    s = Solver(prm)
+    x = sv.init_params + 0.03 * np.random.default_rng(1).standard_normal(sv.init_params.shape)
+    eo = oracle.evaluate(prm, sv, x)
+    eg = s.evaluate(sv, x)
+    for key, tol in (("residuals", JAC_RTOL), ("jacobian", JAC_RTOL), ("gradient", 1e-8)):
+        err = np.abs(eo[key] - eg[key]) / np.maximum(1.0, np.abs(eo[key]))
+        assert np.max(err) < tol, (key, float(np.max(err)), np.unravel_index(np.argmax(err), err.shape))
+    assert np.max(np.abs(eo["cost"] - eg["cost"]) / np.maximum(1.0, eo["cost"])) < 1e-11
+    # critic-major order: the same rows; the rows of steps (and feasibility rows) a scene does not have are zero
+    ec = s.evaluate(sv, x, row_order=1)
+    P = eg["jacobian"].shape[2]
+    for b in (0, sc.B // 2, sc.B - 1):
+        Tb = int(sv.T_scene[b])
+        has = bool(sv.has_people[b])
+        rps = 8 if has else 5
+        nfeas_b = prm.dims(Tb, has)[4] - rps * Tb
+        nfeas = prm.dims(sc.T, has)[4] - rps * sc.T
+        for t in range(sc.T):
+            base = rps * t + min(max(t - 1, 0), nfeas_b)
+            for c in range(rps):
+                want = eg["jacobian"][b, base + c] if t < Tb else np.zeros(P)
+                assert np.array_equal(ec["jacobian"][b, c * sc.T + t], want), (b, t, c)
+        for q in range(nfeas):
+            row = ec["jacobian"][b, rps * sc.T + q]
+            if q >= nfeas_b:
+                assert not row.any()
+            else:
+                assert np.array_equal(row, eg["jacobian"][b, rps * (q + 1) + q + rps]), (b, q)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_solve_with_a_horizon_per_scene(Solver, oracle, name):
+    prm, kw = CASES[name]
+    sc = make_scenes(prm, **kw)
+    sv = sc.with_horizons(horizons(sc.B, sc.T, 11))
+    rg = Solver(prm).solve(sv)
+    rz = oracle.solve(prm, sv, nthreads=16, theta_zero_convention=True)
+    # as in test_gpu_parity: scenes whose LM decisions were firm and whose solve is determined by its inputs at double
+    # precision (an unbounded last block — horizons that the block length does not divide — makes a few ill conditioned)
+    stable = well_conditioned(oracle, prm, sv, rz, nthreads=16, theta_zero_convention=True, samples=2)
+    assert stable.mean() >= 0.95, f"only {stable.sum()}/{len(stable)} scenes are well conditioned"
+    firm = (rz["marginal_decisions"] == 0) & stable
+    assert firm.mean() >= 0.85
+    err = cmd_err(rg["cmds"], rz["cmds"])
+    assert np.max(err[firm]) <= CMD_TOL, (float(np.max(err[firm])), int(np.argmax(np.where(firm, err, 0))))
+    assert np.array_equal(rg["status"][firm], rz["status"][firm])
+    assert np.array_equal(rg["iterations"][firm], rz["iterations"][firm])
+    assert np.max(np.abs(rg["path"][firm] - rz["path"][firm])[:, :, :2]) <= 1e-5
+    assert np.max(np.abs(rg["params"][firm] - rz["params"][firm])) <= CMD_TOL
+    assert np.all(rg["status"][~firm] != 2)
+    # the layout the header documents: nothing behind a scene's own horizon / parameter count
+    for b in range(sc.B):
+        Tb = int(sv.T_scene[b])
+        P_b = prm.dims(Tb, True)[3]
+        assert not rg["cmds"][b, Tb + 1:].any() and not rg["path"][b, Tb + 1:].any()
+        assert not rg["params"][b, P_b:].any()
+
+
+def test_full_horizons_equal_the_plain_batch_bit_for_bit(Solver):
+    """T_scene == T for every scene runs the per-scene instantiation on the plain batch's problem: identical bits."""
+    sc = make_scenes(README, 256, 8, seed=410)
+    s = Solver(README)
+    plain = s.solve(sc)
+    same = s.solve(sc.with_horizons(np.full(sc.B, sc.T, np.int32)))
+    for k in ("params", "cmds", "path", "status", "iterations", "evaluations", "final_cost"):
+        assert np.array_equal(plain[k], same[k]), k
+
+
+def test_a_short_scene_in_a_long_batch_equals_the_batch_of_its_own_horizon(Solver):
+    """Scene b with T_b steps inside a batch of T steps against the same scene handed over as a batch with T = T_b. The
+    surplus parameters stay exactly zero and every sum only gains exact zeros: with the same number of parameter blocks
+    (the same kernel instantiation) the results agree bit for bit; with fewer blocks another instantiation runs, whose
+    compiler-chosen fused multiply-adds may differ in the last bit, and the iteration paths must still coincide."""
+    sc = make_scenes(README, 64, 5, seed=411)
+    Ts = horizons(sc.B, sc.T, 3)
+    sv = sc.with_horizons(Ts)
+    s = Solver(README)
+    rv = s.solve(sv)
+    nb_full = README.dims(sc.T, True)[2]
+    for Tb in (1, 5, 6, 7, 12, 13, 18, 19, 27):
+        idx = np.where(Ts == Tb)[0]
+        nb_b, P_b = README.dims(Tb, True)[2:4]
+        alone = s.solve(sv.cut(idx, Tb, P_b))
+        assert np.array_equal(alone["iterations"], rv["iterations"][idx]), Tb
+        assert np.array_equal(alone["status"], rv["status"][idx]), Tb
+        if nb_b == nb_full:
+            assert np.array_equal(alone["params"], rv["params"][idx][:, :P_b]), Tb
+            assert np.array_equal(alone["cmds"], rv["cmds"][idx][:, :Tb + 1]), Tb
+            assert np.array_equal(alone["final_cost"], rv["final_cost"][idx]), Tb
+        else:
+            assert np.max(np.abs(alone["params"] - rv["params"][idx][:, :P_b])) <= 1e-9, Tb
+            assert np.allclose(alone["final_cost"], rv["final_cost"][idx], rtol=1e-10), Tb
+
+
+def test_device_pointer_path_and_bad_horizons(Solver):
+    import torch
+    from nav2_social_mpc_controller_amd.solver import SmpcError
+    sc = make_scenes(README, 128, 4, seed=412)
+    Ts = horizons(sc.B, sc.T, 5)
+    sv = sc.with_horizons(Ts)
+    s = Solver(README)
+    host = s.solve(sv)
+    sb, tens = sv.to_device()
+    sb.T_scene = tens["T_scene"].data_ptr()
+    rb, rt = s.alloc_results(sc.B, sc.T)
+    s.solve_device(sb, rb)
+    torch.cuda.synchronize()
+    assert np.array_equal(rt["cmds"].cpu().numpy(), host["cmds"])
+    assert np.array_equal(rt["iterations"].cpu().numpy(), host["iterations"])
+    bad = sc.with_horizons(Ts)
+    bad.T_scene = bad.T_scene.copy()
+    bad.T_scene[3] = sc.T + 1
+    with pytest.raises(SmpcError):
+        s.solve(bad)
