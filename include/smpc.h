@@ -60,7 +60,8 @@ enum smpc_reason {
   SMPC_REASON_MIN_RADIUS = 4,
   SMPC_REASON_MAX_ITERATIONS = 5,
   SMPC_REASON_INVALID_STEPS = 6,
-  SMPC_REASON_EVAL_FAILED = 7
+  SMPC_REASON_EVAL_FAILED = 7,
+  SMPC_REASON_SHORT_PATH = 8 /* T_scene[b] < 1: "Path has less than 2 points, cannot optimize" (src/optimizer.cpp:158-162) */
 };
 
 /* API return codes (never exceptions). */
@@ -151,7 +152,8 @@ typedef struct smpc_scene_batch {
    * feasibility-row counts that follow from them. Every array keeps the batch's strides (T + 1 poses, P parameters): of
    * path_pts / people the first T_b + 1 entries of scene b are read (its final point is path_pts[b][T_b]), of
    * init_params the first P_b; results: params[P_b..P) = 0, cmds / path rows beyond T_b are written as zeros.
-   * NULL: every scene has T steps. */
+   * T_scene[b] < 1 (a path of fewer than two poses, for which Optimizer::optimize returns false, :158-162): status
+   * SMPC_FAILURE with reason SMPC_REASON_SHORT_PATH. NULL: every scene has T steps. */
   const int32_t* T_scene; /* [B] */
 } smpc_scene_batch;
 
@@ -259,6 +261,11 @@ typedef struct smpc_memory_batch {
   double* prev_path;  /* [B][T+1][3] previous_path.poses: x, y, yaw */
   double* prev_cmds;  /* [B][T+1][2] previous_cmds: linear.x, angular.z */
   int32_t* valid;     /* [B] 0 while previous_path.poses.size() == 0 (src/optimizer.cpp:177) */
+  int32_t* length;    /* [B][2] previous_path.poses.size(), previous_cmds.size() of each record (as far as its T + 1 rows
+                         hold them), kept up to date by smpc_format_to_optimize_batch and smpc_memory_store_batch: needed
+                         when the scenes have horizons of their own (smpc_format_batch.n_poses), since format_to_optimize
+                         blends pose i only while i < previous_path.poses.size() (:504). NULL: fixed horizon, every
+                         record holds T + 1 of both. */
 } smpc_memory_batch;
 
 /* Optimizer::people_to_status (src/optimizer.cpp:454-482) for B scenes: people_msgs::Person position / velocity ->
@@ -303,6 +310,14 @@ typedef struct smpc_format_batch {
   const double* cmds;  /* [B][path_rows][2] trajectorizer commands (entries 0..T are read; T only to seed an empty memory) */
   const double* speed; /* [B][2] current robot twist linear.x, angular.z */
   smpc_memory_batch memory;
+  /* Horizons per scene (optional): n_poses[b] = poses of the incoming path of scene b (smpc_trajectorize_out.n_poses;
+   * its commands: one fewer), max_poses = (int)round(max_time / time_step) of the cut (:491-497): a path of more than
+   * max_poses poses keeps max_poses - 1, any other path all of its poses (one of exactly max_poses poses is NOT cut: its
+   * horizon is one step longer than that of the longer paths — size T for it: T = max_poses - 1). The scene's horizon
+   * T_b = kept poses - 1 is returned in smpc_format_out.T_scene; rows a scene does not have are written as zeros.
+   * n_poses == NULL: every path is taken to have T + 1 poses, all of them kept. */
+  const int32_t* n_poses; /* [B] */
+  int32_t max_poses;      /* 0: no cut */
 } smpc_format_batch;
 
 typedef struct smpc_format_out {
@@ -310,7 +325,8 @@ typedef struct smpc_format_out {
   double* pose0;        /* [B][3]      -> smpc_scene_batch.pose0 */
   double* init_params;  /* [B][P]      -> smpc_scene_batch.init_params (P from smpc_dims) */
   double* path_pts;     /* [B][T+1][2] -> smpc_scene_batch.path_pts */
-  double* goal_yaw;     /* [B]         -> smpc_scene_batch.goal_yaw */
+  double* goal_yaw;     /* [B]         -> smpc_scene_batch.goal_yaw: heading of the scene's last kept pose */
+  int32_t* T_scene;     /* [B]         -> smpc_scene_batch.T_scene (0: fewer than two poses); may be NULL */
 } smpc_format_out;
 
 int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, smpc_format_out* out);
@@ -319,7 +335,8 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
  * usable (status != SMPC_FAILURE; the reference returns before the store otherwise, :384-388) keep the optimised path
  * and commands for the next call. path / cmds / status are smpc_result_batch arrays. */
 int smpc_memory_store_batch(smpc_handle* h, int32_t B, int32_t T, int32_t on_device, const int32_t* status,
-                            const double* path, const double* cmds, smpc_memory_batch* memory);
+                            const double* path, const double* cmds, smpc_memory_batch* memory,
+                            const int32_t* T_scene /* [B] horizons of the solve (its T_scene), or NULL: T everywhere */);
 
 /* ---- initial-guess generator -------------------------------------------------------------------
  * PathTrajectorizer::trajectorize (src/path_trajectorizer.cpp:120-288; motion model path_trajectorizer.hpp:106-135)
@@ -392,16 +409,19 @@ typedef struct smpc_plan_window_batch {
 int smpc_transform_global_plan_batch(smpc_handle* h, const smpc_plan_window_batch* in, double* window, int32_t* window_len,
                                      int32_t* error);
 
-/* The command SocialMPCController::computeVelocityCommands returns (src/social_mpc_controller.cpp:176-256; SURVEY §8 row
+/* The command SocialMPCController::computeVelocityCommands returns (src/social_mpc_controller.cpp:171-256; SURVEY §8 row
  * f4) for B robots: cmds[0] of a usable solve (:250-256), the trajectorizer's first command when the optimisation was
- * not usable (:241-245) or — a limit of the fixed-T batch — when the trajectorized path was shorter than T + 1 poses,
- * and (0.1, 0) when trajectorize returned false (:180-189). source [B]: 0 optimised, 1 trajectorizer command,
- * 2 the 0.1 m/s fallback. */
+ * not usable (:241-245), (0.1, 0) when trajectorize returned false (:180-189), and nothing at all when
+ * transformGlobalPlan threw (src/path_handler.cpp:44-47, 100-103: the exception leaves computeVelocityCommands and the
+ * controller server publishes no command for the cycle). source [B]: 0 optimised, 1 trajectorizer command, 2 the
+ * 0.1 m/s fallback, 3 no command (cmd_vel is written as zeros). A path shorter than T + 1 poses is not a fallback case:
+ * it is solved with its own horizon (smpc_format_batch.n_poses -> T_scene). */
 int smpc_select_command_batch(smpc_handle* h, int32_t B, int32_t T, int32_t traj_rows, int32_t on_device,
                               const int32_t* traj_n_poses /* [B]; NULL: every path is complete */,
                               const double* traj_cmds /* [B][traj_rows][2] */, const int32_t* status /* [B] */,
                               const double* cmds /* [B][T+1][2] */, double* cmd_vel /* [B][2] */,
-                              int32_t* source /* [B]; may be NULL */);
+                              int32_t* source /* [B]; may be NULL */,
+                              const int32_t* window_error /* [B] enum smpc_window_error of this cycle; may be NULL */);
 
 /* Diagnostic: evaluates the elementary functions the sweep uses (csrc/smpc_math.hpp: table-driven exp / atan2 /
  * sincos, refined reciprocal / rsqrt, and the raw hardware estimates behind them) on n host-side arguments, so that

@@ -123,6 +123,7 @@ class SmpcMemoryBatch(C.Structure):
         ("prev_path", C.c_void_p),
         ("prev_cmds", C.c_void_p),
         ("valid", C.c_void_p),
+        ("length", C.c_void_p),
     ]
 
 
@@ -139,6 +140,8 @@ class SmpcFormatBatch(C.Structure):
         ("cmds", C.c_void_p),
         ("speed", C.c_void_p),
         ("memory", SmpcMemoryBatch),
+        ("n_poses", C.c_void_p),
+        ("max_poses", C.c_int32),
     ]
 
 
@@ -149,6 +152,7 @@ class SmpcFormatOut(C.Structure):
         ("init_params", C.c_void_p),
         ("path_pts", C.c_void_p),
         ("goal_yaw", C.c_void_p),
+        ("T_scene", C.c_void_p),
     ]
 
 

@@ -616,13 +616,15 @@ __device__ inline void load_scene(Ctx& c, int scene) {
   const int T = k.T, N = k.N, sl = c.sl;
   int Th = T;  // the scene's own horizon
   if (kVT) {
-    if (k.T_scene) Th = min(max(k.T_scene[scene], 1), T);
+    const int Traw = k.T_scene ? k.T_scene[scene] : T;
+    Th = min(max(Traw, 1), T);
     const int CH = min(k.prm.control_horizon, Th);
     const int bl = max(min(k.prm.parameter_block_length, CH), 1);
     int* z = reinterpret_cast<int*>(c.lds + c.L.hz);
     z[0] = Th; z[1] = CH; z[2] = bl; z[3] = (CH - 1) / bl;
     z[4] = max(min(CH / bl, Th) - 1, 0);  // src/optimizer.cpp:364
     z[5] = CH / bl;                       // :373
+    z[6] = Traw < 1 ? 1 : 0;              // a path of fewer than two poses: Optimizer::optimize returns false (:158-162)
   }
   const size_t s = scene;
   c.scene = scene;

@@ -12,18 +12,22 @@ namespace smpc {
 
 struct FormatParams {
   int B, T, nb, P, rows;  // rows: pose stride of path / cmds
+  int max_poses;          // round(max_time / time_step) of the cut (:492-497); 0: no cut
   float time_step, current_path_w, current_cmds_w;
-  const double* path;   // [B][T+1][3]
-  const double* cmds;   // [B][T+1][2]
+  const double* path;   // [B][rows][3]
+  const double* cmds;   // [B][rows][2]
   const double* speed;  // [B][2]
+  const int32_t* n_poses;  // [B] poses of each incoming path, or null: every path has (at least) T + 1
   double* prev_path;    // [B][T+1][3]
   double* prev_cmds;    // [B][T+1][2]
   int32_t* valid;       // [B]
+  int32_t* length;      // [B][2] poses / commands a record holds, or null (fixed horizon: T + 1 of both)
   double* robot_status; // [B][T+1][6]
   double* pose0;        // [B][3]
   double* init_params;  // [B][P]
   double* path_pts;     // [B][T+1][2]
   double* goal_yaw;     // [B]
+  int32_t* T_scene;     // [B] or null
 };
 
 // tf2 Quaternion::setRPY(0, 0, yaw) -> toMsg -> tf2::getYaw for a pure-yaw quaternion (x = y = 0).
@@ -31,6 +35,14 @@ __device__ inline double format_yaw_roundtrip(double yaw) {
   double sz, cz;
   sincos(yaw * 0.5, &sz, &cz);
   return atan2(2.0 * (cz * sz), cz * cz - sz * sz);
+}
+
+// poses of scene s as they arrive (n), poses format_to_optimize keeps (kept: the cut of :492-497, at most the stride)
+__device__ inline void format_lengths(const FormatParams& p, int s, int& n, int& kept) {
+  const int Tp = p.T + 1;
+  n = p.n_poses ? max(p.n_poses[s], 0) : Tp;
+  kept = (p.max_poses > 0 && n > p.max_poses) ? p.max_poses - 1 : n;
+  kept = min(kept, Tp);
 }
 
 // grid: ceil(B * (T + 1) / 256) blocks of 256 lanes; lane = (scene, pose index i)
@@ -42,33 +54,51 @@ __global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) 
   const int s = (int)(gid / Tp), i = (int)(gid - (long long)s * Tp);
   const size_t e = (size_t)s * Tp + i;          // element of the dense [B][T+1] arrays
   const size_t ei = (size_t)s * p.rows + i;      // element of the incoming path / cmds
-  const double cx = p.path[3 * ei], cy = p.path[3 * ei + 1], cyaw = p.path[3 * ei + 2];
-  const double cv = p.cmds[2 * ei], cw = p.cmds[2 * ei + 1];
-  // memory.previous_path.poses.size() == 0: previous := current (:177-183); the blend below then runs against that copy
+  int n, kept;
+  format_lengths(p, s, n, kept);
+  const int ncmd = p.n_poses ? max(n - 1, 0) : Tp;  // commands that arrive: one per step taken (trajectorize :262-269)
   const bool have = p.valid[s] != 0;
-  const double px = have ? p.prev_path[3 * e] : cx, py = have ? p.prev_path[3 * e + 1] : cy;
-  const double pyaw = have ? p.prev_path[3 * e + 2] : cyaw;
+  // memory.previous_path.poses.size() == 0: previous := current, the whole incoming path and commands (:177-183; as
+  // much of them as the record's T + 1 rows hold); the blend below then runs against that copy
+  const int plen = have ? (p.length ? p.length[2 * s] : Tp) : min(n, Tp);
+  const int clen = have ? (p.length ? p.length[2 * s + 1] : Tp) : min(ncmd, Tp);
   if (!have) {
-    p.prev_path[3 * e] = cx; p.prev_path[3 * e + 1] = cy; p.prev_path[3 * e + 2] = cyaw;
-    p.prev_cmds[2 * e] = cv; p.prev_cmds[2 * e + 1] = cw;
+    if (i < plen) { p.prev_path[3 * e] = p.path[3 * ei]; p.prev_path[3 * e + 1] = p.path[3 * ei + 1]; p.prev_path[3 * e + 2] = p.path[3 * ei + 2]; }
+    if (i < clen) { p.prev_cmds[2 * e] = p.cmds[2 * ei]; p.prev_cmds[2 * e + 1] = p.cmds[2 * ei + 1]; }
   }
+  double* r = p.robot_status + 6 * e;
+  if (i == 0 && p.T_scene) p.T_scene[s] = max(kept - 1, 0);  // optim_velocities.size() after the pop_back (:237)
+  if (i >= kept) {  // rows the scene does not have: defined content
+    r[0] = r[1] = r[2] = r[3] = r[4] = r[5] = 0.0;
+    p.path_pts[2 * e] = 0.0; p.path_pts[2 * e + 1] = 0.0;
+    if (i < p.nb) { p.init_params[(size_t)s * p.P + 2 * i] = 0.0; p.init_params[(size_t)s * p.P + 2 * i + 1] = 0.0; }
+    if (kept == 0 && i == 0) { p.pose0[3 * s] = p.pose0[3 * s + 1] = p.pose0[3 * s + 2] = 0.0; p.goal_yaw[s] = 0.0; }
+    return;
+  }
+  const double cx = p.path[3 * ei], cy = p.path[3 * ei + 1], cyaw = p.path[3 * ei + 2];
   const double wp = (double)p.current_path_w, wc = (double)p.current_cmds_w;
-  // previous_path is never empty here and holds T + 1 poses, so every pose is blended (:504-520)
-  const double x = wp * cx + (1.0 - wp) * px;
-  const double y = wp * cy + (1.0 - wp) * py;
-  const double yaw = format_yaw_roundtrip(wp * cyaw + (1.0 - wp) * pyaw);
+  double x = cx, y = cy, yaw = cyaw;
+  if (i < plen) {  // "!previous_path.poses.empty() && i < previous_path.poses.size()" (:504): blended, yaw through setRPY
+    const double px = have ? p.prev_path[3 * e] : cx, py = have ? p.prev_path[3 * e + 1] : cy;
+    const double pyaw = have ? p.prev_path[3 * e + 2] : cyaw;
+    x = wp * cx + (1.0 - wp) * px;
+    y = wp * cy + (1.0 - wp) * py;
+    yaw = format_yaw_roundtrip(wp * cyaw + (1.0 - wp) * pyaw);
+  }
   double lv, av;
   if (i == 0) {
     lv = p.speed[2 * s]; av = p.speed[2 * s + 1];  // :529-533
   } else {
-    // cmds[i - 1] against previous_cmds[i - 1] (:537-545)
+    // cmds[i - 1] against previous_cmds[i - 1] (:537-545). The reference indexes previous_cmds without a bound: a
+    // record shorter than i (a plan that grew by more than a pose since the last solve) is undefined behaviour there;
+    // here the current command stands alone in that case.
     const size_t em = e - 1;
     const double cv1 = p.cmds[2 * (ei - 1)], cw1 = p.cmds[2 * (ei - 1) + 1];
-    const double pv1 = have ? p.prev_cmds[2 * em] : cv1, pw1 = have ? p.prev_cmds[2 * em + 1] : cw1;
+    const bool in = i - 1 < clen;
+    const double pv1 = (have && in) ? p.prev_cmds[2 * em] : cv1, pw1 = (have && in) ? p.prev_cmds[2 * em + 1] : cw1;
     lv = wc * cv1 + (1.0 - wc) * pv1;
     av = wc * cw1 + (1.0 - wc) * pw1;
   }
-  double* r = p.robot_status + 6 * e;
   r[0] = x; r[1] = y; r[2] = yaw;
   r[3] = (double)((float)i * p.time_step);  // unsigned * float product (:523)
   r[4] = lv; r[5] = av;
@@ -79,15 +109,22 @@ __global__ __launch_bounds__(256) void smpc_format_kernel(const FormatParams p) 
     p.pose0[3 * s + 2] = format_yaw_roundtrip(yaw);  // evolving_poses[0]: setRPY(0, 0, yaw), read back with getYaw
   }
   if (i < p.nb) { p.init_params[(size_t)s * p.P + 2 * i] = lv; p.init_params[(size_t)s * p.P + 2 * i + 1] = av; }
-  if (i == p.T) p.goal_yaw[s] = yaw;
+  if (i == kept - 1) p.goal_yaw[s] = yaw;
 }
 
 // Second pass of the format step: mark freshly filled memory records valid (after every lane of the first kernel has
-// read the flag).
-__global__ __launch_bounds__(256) void smpc_format_mark_kernel(int B, int32_t* valid) {
+// read the flag) and note how much they hold.
+__global__ __launch_bounds__(256) void smpc_format_mark_kernel(const FormatParams p) {
   SMPC_CHAIN_PRIORITY();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < B) valid[s] = 1;
+  if (s >= p.B || p.valid[s] != 0) return;
+  int n, kept;
+  format_lengths(p, s, n, kept);
+  p.valid[s] = 1;
+  if (p.length) {
+    p.length[2 * s] = min(n, p.T + 1);
+    p.length[2 * s + 1] = min(p.n_poses ? max(n - 1, 0) : p.T + 1, p.T + 1);
+  }
 }
 
 struct PeopleParams {
@@ -159,9 +196,11 @@ struct StoreParams {
   const int32_t* status;
   const double* path;  // [B][T+1][3] smpc_result_batch.path
   const double* cmds;  // [B][T+1][2] smpc_result_batch.cmds
+  const int32_t* T_scene;  // [B] or null: every scene has T steps
   double* prev_path;
   double* prev_cmds;
   int32_t* valid;
+  int32_t* length;     // [B][2] or null
 };
 
 __global__ __launch_bounds__(256) void smpc_memory_store_kernel(const StoreParams p) {
@@ -169,12 +208,17 @@ __global__ __launch_bounds__(256) void smpc_memory_store_kernel(const StoreParam
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int Tp = p.T + 1;
   if (gid >= (long long)p.B * Tp) return;
-  const int s = (int)(gid / Tp);
+  const int s = (int)(gid / Tp), i = (int)(gid - (long long)s * Tp);
   if (p.status[s] == 2 /* SMPC_FAILURE */) return;  // the reference returns false before the store (:384-388)
+  const int Tb = p.T_scene ? min(max(p.T_scene[s], 1), p.T) : p.T;  // the path and the commands of a solve have Tb + 1 entries
+  if (i > Tb) return;
   const size_t e = (size_t)gid;
   p.prev_path[3 * e] = p.path[3 * e]; p.prev_path[3 * e + 1] = p.path[3 * e + 1]; p.prev_path[3 * e + 2] = p.path[3 * e + 2];
   p.prev_cmds[2 * e] = p.cmds[2 * e]; p.prev_cmds[2 * e + 1] = p.cmds[2 * e + 1];
-  if (gid - (long long)s * Tp == 0) p.valid[s] = 1;
+  if (i == 0) {
+    p.valid[s] = 1;
+    if (p.length) { p.length[2 * s] = Tb + 1; p.length[2 * s + 1] = Tb + 1; }
+  }
 }
 
 struct SelectParams {
@@ -183,11 +227,12 @@ struct SelectParams {
   const double* traj_cmds; // [B][rows][2]
   const int32_t* status;   // [B]
   const double* cmds;      // [B][T+1][2]
+  const int32_t* window_error;  // [B] or null
   double* cmd_vel;         // [B][2]
   int32_t* source;         // [B] or null
 };
 
-// computeVelocityCommands' choice of the returned command (src/social_mpc_controller.cpp:180-189, 241-245, 250-256).
+// computeVelocityCommands' choice of the returned command (src/social_mpc_controller.cpp:171-189, 241-245, 250-256).
 __global__ __launch_bounds__(256) void smpc_select_command_kernel(const SelectParams p) {
   SMPC_CHAIN_PRIORITY();
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,9 +240,13 @@ __global__ __launch_bounds__(256) void smpc_select_command_kernel(const SelectPa
   const int n = p.traj_n ? p.traj_n[s] : p.T + 1;
   int src;
   double v, w;
-  if (n <= 0) {  // trajectorize() returned false: "using fallback cmd_vel"
+  if (p.window_error && p.window_error[s] != 0) {
+    // transformGlobalPlan threw (src/path_handler.cpp:44-47, 100-103): computeVelocityCommands does not return, the
+    // controller server gets the exception and no command goes out in this cycle
+    src = 3; v = 0.0; w = 0.0;
+  } else if (n <= 0) {  // trajectorize() returned false: "using fallback cmd_vel" (:180-189)
     src = 2; v = 0.1; w = 0.0;
-  } else if (n < p.T + 1 || p.status[s] == 2 /* SMPC_FAILURE */) {  // cmds = init_cmds
+  } else if (p.status[s] == 2 /* SMPC_FAILURE */) {  // optimize() returned false: cmds = init_cmds (:241-245)
     src = 1; v = p.traj_cmds[(size_t)s * p.rows * 2]; w = p.traj_cmds[(size_t)s * p.rows * 2 + 1];
   } else {
     src = 0; v = p.cmds[(size_t)s * (p.T + 1) * 2]; w = p.cmds[(size_t)s * (p.T + 1) * 2 + 1];

@@ -643,15 +643,22 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
   const size_t rows = in->path_rows > 0 ? (size_t)in->path_rows : Tp;
   if (rows < Tp) { set_error("path_rows < T + 1"); return SMPC_ERR_INVALID_ARG; }
   p.B = in->B; p.T = in->T; p.nb = d.nb; p.P = d.P; p.rows = (int)rows;
+  p.max_poses = in->max_poses > 0 ? in->max_poses : 0;
   p.time_step = in->time_step; p.current_path_w = in->current_path_w; p.current_cmds_w = in->current_cmds_w;
+  if (in->n_poses && !in->memory.length) {
+    set_error("n_poses needs memory.length: records of scenes with horizons of their own differ in size"); return SMPC_ERR_INVALID_ARG;
+  }
   Staging st(h);
   if (in->on_device) {
-    p.path = in->path; p.cmds = in->cmds; p.speed = in->speed;
-    p.prev_path = in->memory.prev_path; p.prev_cmds = in->memory.prev_cmds; p.valid = in->memory.valid;
+    p.path = in->path; p.cmds = in->cmds; p.speed = in->speed; p.n_poses = in->n_poses;
+    p.prev_path = in->memory.prev_path; p.prev_cmds = in->memory.prev_cmds; p.valid = in->memory.valid; p.length = in->memory.length;
     p.robot_status = out->robot_status; p.pose0 = out->pose0; p.init_params = out->init_params;
-    p.path_pts = out->path_pts; p.goal_yaw = out->goal_yaw;
+    p.path_pts = out->path_pts; p.goal_yaw = out->goal_yaw; p.T_scene = out->T_scene;
   } else {
     const double* c = nullptr; const int32_t* ci = nullptr;
+    SMPC_TRY(st.up(in->n_poses, B, &p.n_poses, h->stream));
+    SMPC_TRY(st.up(static_cast<const int32_t*>(in->memory.length), B * 2, &ci, h->stream)); p.length = const_cast<int32_t*>(ci);
+    SMPC_TRY(st.out(out->T_scene, B, &p.T_scene));
     SMPC_TRY(st.up(in->path, B * rows * 3, &p.path, h->stream));
     SMPC_TRY(st.up(in->cmds, B * rows * 2, &p.cmds, h->stream));
     SMPC_TRY(st.up(in->speed, B * 2, &p.speed, h->stream));
@@ -669,7 +676,7 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(smpc::smpc_format_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(smpc::smpc_format_mark_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, (int)B, p.valid);
+    hipLaunchKernelGGL(smpc::smpc_format_mark_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -683,13 +690,15 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
     SMPC_TRY(down(in->memory.prev_path, p.prev_path, B * Tp * 3, h->stream));
     SMPC_TRY(down(in->memory.prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
     SMPC_TRY(down(in->memory.valid, p.valid, B, h->stream));
+    SMPC_TRY(down(in->memory.length, p.length, B * 2, h->stream));
+    SMPC_TRY(down(out->T_scene, p.T_scene, B, h->stream));
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   return SMPC_OK;
 }
 
 int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_device, const int32_t* status,
-                            const double* path, const double* cmds, smpc_memory_batch* memory) {
+                            const double* path, const double* cmds, smpc_memory_batch* memory, const int32_t* T_scene) {
   if (!h || !status || !path || !cmds || !memory || !memory->prev_path || !memory->prev_cmds || !memory->valid) {
     set_error("null handle / array / memory record"); return SMPC_ERR_INVALID_ARG;
   }
@@ -700,11 +709,16 @@ int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_de
   std::memset(&p, 0, sizeof(p));
   p.B = B_; p.T = T;
   Staging st(h);
+  if (T_scene && !memory->length) {
+    set_error("T_scene needs memory.length: records of scenes with horizons of their own differ in size"); return SMPC_ERR_INVALID_ARG;
+  }
   if (on_device) {
-    p.status = status; p.path = path; p.cmds = cmds;
-    p.prev_path = memory->prev_path; p.prev_cmds = memory->prev_cmds; p.valid = memory->valid;
+    p.status = status; p.path = path; p.cmds = cmds; p.T_scene = T_scene;
+    p.prev_path = memory->prev_path; p.prev_cmds = memory->prev_cmds; p.valid = memory->valid; p.length = memory->length;
   } else {
     const double* c = nullptr; const int32_t* ci = nullptr;
+    SMPC_TRY(st.up(T_scene, B, &p.T_scene, h->stream));
+    SMPC_TRY(st.up(static_cast<const int32_t*>(memory->length), B * 2, &ci, h->stream)); p.length = const_cast<int32_t*>(ci);
     SMPC_TRY(st.up(status, B, &p.status, h->stream));
     SMPC_TRY(st.up(path, B * Tp * 3, &p.path, h->stream));
     SMPC_TRY(st.up(cmds, B * Tp * 2, &p.cmds, h->stream));
@@ -724,6 +738,7 @@ int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_de
     SMPC_TRY(down(memory->prev_path, p.prev_path, B * Tp * 3, h->stream));
     SMPC_TRY(down(memory->prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
     SMPC_TRY(down(memory->valid, p.valid, B, h->stream));
+    SMPC_TRY(down(memory->length, p.length, B * 2, h->stream));
     SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
   }
   return SMPC_OK;
@@ -845,7 +860,8 @@ int smpc_transform_global_plan_batch(smpc_handle* h, const smpc_plan_window_batc
 }
 
 int smpc_select_command_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t traj_rows, int32_t on_device, const int32_t* traj_n_poses,
-                              const double* traj_cmds, const int32_t* status, const double* cmds, double* cmd_vel, int32_t* source) {
+                              const double* traj_cmds, const int32_t* status, const double* cmds, double* cmd_vel, int32_t* source,
+                              const int32_t* window_error) {
   if (!h || !traj_cmds || !status || !cmds || !cmd_vel) { set_error("null handle / array"); return SMPC_ERR_INVALID_ARG; }
   if (B_ < 0 || T < 1 || traj_rows < 1) { set_error("bad B / T / traj_rows"); return SMPC_ERR_INVALID_ARG; }
   SMPC_HIP_CHECK(hipSetDevice(h->device));
@@ -856,7 +872,9 @@ int smpc_select_command_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t tra
   Staging st(h);
   if (on_device) {
     p.traj_n = traj_n_poses; p.traj_cmds = traj_cmds; p.status = status; p.cmds = cmds; p.cmd_vel = cmd_vel; p.source = source;
+    p.window_error = window_error;
   } else {
+    SMPC_TRY(st.up(window_error, B, &p.window_error, h->stream));
     SMPC_TRY(st.up(traj_n_poses, B, &p.traj_n, h->stream));
     SMPC_TRY(st.up(traj_cmds, B * (size_t)traj_rows * 2, &p.traj_cmds, h->stream));
     SMPC_TRY(st.up(status, B, &p.status, h->stream));

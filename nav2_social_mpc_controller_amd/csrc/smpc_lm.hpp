@@ -667,7 +667,9 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
       ++R.evals;
       sv[S_COST] = val;
       sv[S_INITIAL_COST] = val;
-      if (!finite) {
+      if (kVT && reinterpret_cast<const int*>(c.lds + c.L.hz)[6] != 0) {
+        R.status = SMPC_FAILURE; R.reason = SMPC_REASON_SHORT_PATH; R.phase = PH_DONE;  // "Path has less than 2 points"
+      } else if (!finite) {
         R.status = SMPC_FAILURE; R.reason = SMPC_REASON_EVAL_FAILED; R.phase = PH_DONE;
       } else {
         if (act) sc[q] = 1.0 / (1.0 + sqrt(GH.base[q * GH.ld + q]));  // Jacobi scaling (A.5)

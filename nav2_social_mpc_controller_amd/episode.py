@@ -55,6 +55,8 @@ class TickRecord:
     persons: np.ndarray = None      # [B,Np,5] world people (px, py, vx, vy, vz) the tick started from
     person_count: np.ndarray = None
     has_people: np.ndarray = None
+    T_scene: np.ndarray = None      # [B] horizon every robot was solved with (plan episodes: from its own path length)
+    window_err: np.ndarray = None   # [B] smpc_window_error of the tick's transformGlobalPlan (plan_window episodes)
 
 
 class BatchEpisode:
@@ -82,6 +84,13 @@ class BatchEpisode:
         # library kernels and the few torch ops of the world model share one stream, so they are ordered
         self.solver.set_stream(torch.cuda.current_stream(self.dev).cuda_stream)
         B, T, N = scenes.B, scenes.T, scenes.N
+        if plan is not None:
+            # Plan mode: every robot is solved with the horizon its own trajectorized path gives it (smpc_format_batch.n_poses
+            # -> T_scene). The arrays are sized for the longest one: a path of exactly max_poses = round(max_time / dt)
+            # poses is not cut by format_to_optimize (src/optimizer.cpp:491-497) and so has one step more than the longer,
+            # cut, paths: T = max_poses - 1 = rollout_steps + 1.
+            assert T == params.rollout_steps
+            T = T + 1
         self.B, self.T, self.N = B, T, N
         CH, bl, nb, P, M, _ = params.dims(T, True)
         self.P = P
@@ -112,10 +121,13 @@ class BatchEpisode:
         self.mem_path = torch.zeros((B, T + 1, 3), **f64)
         self.mem_cmds = torch.zeros((B, T + 1, 2), **f64)
         self.mem_valid = torch.zeros(B, dtype=torch.int32, device=self.dev)
+        self.mem_length = torch.zeros((B, 2), dtype=torch.int32, device=self.dev)   # poses / commands of every record
+        self.T_scene = torch.full((B,), T, dtype=torch.int32, device=self.dev)      # horizon of every robot this tick
+        self.max_poses = int(np.round(np.float32(params.max_time) / np.float32(params.time_step)))
         # per-tick buffers
         self.traj = traj_params
         if plan is not None:
-            assert traj_params is not None and traj_params.max_steps >= T
+            assert traj_params is not None and traj_params.max_steps + 1 >= T + 1
             self.plan = torch.from_numpy(np.ascontiguousarray(plan, np.float64)).to(self.dev)
             self.plan_len = torch.from_numpy(np.ascontiguousarray(plan_len, np.int32)).to(self.dev)
             self.rows = traj_params.max_steps + 1
@@ -143,14 +155,13 @@ class BatchEpisode:
         self.proj_error = torch.zeros(B, dtype=torch.int32, device=self.dev)
         self.rb, self.res = self.solver.alloc_results(B, T, self.dev)
         self.cmd_vel = torch.zeros((B, 2), **f64)                      # the command returned to the robot this tick
-        self.cmd_source = torch.zeros(B, dtype=torch.int32, device=self.dev)  # 0 optimised, 1 trajectorizer, 2 creep
+        self.cmd_source = torch.zeros(B, dtype=torch.int32, device=self.dev)  # 0 optimised, 1 trajectorizer, 2 creep, 3 none
         self.order_hint = order_hint
         self.graph = None
         self.gstream = None
         # queue order for the next solve (from the last solve's sweep counts; index order before the first one)
         self.order = torch.arange(B, dtype=torch.int32, device=self.dev)
         self.ticks = 0
-        self.parked = None  # plan mode: scenes parked in the last tick (bool tensor)
 
     # -- trajectorizer (row f3) on the global plans, or the arc stand-in: v = 0.6, w = w_ref from the current pose --
     def _plan(self, timing: dict = None):
@@ -186,11 +197,12 @@ class BatchEpisode:
     def _memory_c(self) -> SmpcMemoryBatch:
         mb = SmpcMemoryBatch()
         mb.prev_path, mb.prev_cmds, mb.valid = self.mem_path.data_ptr(), self.mem_cmds.data_ptr(), self.mem_valid.data_ptr()
+        mb.length = self.mem_length.data_ptr()
         return mb
 
     def _memory_host(self) -> dict:
         return {"prev_path": self.mem_path.cpu().numpy().copy(), "prev_cmds": self.mem_cmds.cpu().numpy().copy(),
-                "valid": self.mem_valid.cpu().numpy().copy()}
+                "valid": self.mem_valid.cpu().numpy().copy(), "length": self.mem_length.cpu().numpy().copy()}
 
     def tick(self, record: bool = False, timing: dict = None):
         """One controller period for all B robots. Returns a TickRecord when `record`, else None. `timing`: a dict
@@ -235,9 +247,12 @@ class BatchEpisode:
         fb.current_path_w, fb.current_cmds_w = float(prm.current_path_weight), float(prm.current_cmds_weight)
         fb.path, fb.cmds, fb.speed = self.plan_path.data_ptr(), self.plan_cmds.data_ptr(), self.speed.data_ptr()
         fb.memory = self._memory_c()
+        if self.plan is not None:  # every robot with the horizon of its own trajectorized path
+            fb.n_poses, fb.max_poses = self.traj_n.data_ptr(), self.max_poses
         fo = SmpcFormatOut()
         fo.robot_status, fo.pose0, fo.init_params = self.robot_status.data_ptr(), self.pose0.data_ptr(), self.init_params.data_ptr()
         fo.path_pts, fo.goal_yaw = self.path_pts.data_ptr(), self.goal_yaw.data_ptr()
+        fo.T_scene = self.T_scene.data_ptr()
         s.format_device(fb, fo)
         if timing is not None:
             timing["format_ms"] = s.last_kernel_ms()
@@ -263,23 +278,23 @@ class BatchEpisode:
         sb.costmap_origin, sb.resolution = self.costmap_origin.data_ptr(), self.resolution
         if self.order_hint:
             sb.order = self.order.data_ptr()  # longest scenes of the previous period first
+        if self.plan is not None:
+            sb.T_scene = self.T_scene.data_ptr()
         s.solve_device(sb, self.rb)
         if timing is not None:
             timing["solve_ms"] = s.last_kernel_ms()
         if self.order_hint:
             self.order.copy_(BatchSolver.longest_first(self.res["evaluations"]))
-        # scenes whose trajectorized path is shorter than the horizon (the robot is about to reach the end of its plan)
-        # would need a smaller T than the batch has: they are parked — treated like an unusable solve from here on
-        if self.plan is not None:
-            parked = self.traj_n < (T + 1)
-            self.res["status"].masked_fill_(parked, 2)
-            self.parked = parked
-        # 4. memory store (usable solves only)
+        # 4. memory store (usable solves only; T_scene + 1 poses and commands of each)
         mb = self._memory_c()
-        s.memory_store_device(B, T, self.res["status"].data_ptr(), self.res["path"].data_ptr(), self.res["cmds"].data_ptr(), mb)
+        s.memory_store_device(B, T, self.res["status"].data_ptr(), self.res["path"].data_ptr(), self.res["cmds"].data_ptr(), mb,
+                              self.T_scene.data_ptr() if self.plan is not None else 0)
         if timing is not None:
             timing["store_ms"] = s.last_kernel_ms()
         if record:
+            rec.update(T_scene=self.T_scene.cpu().numpy().copy())
+            if self.plan_window is not None:
+                rec.update(window_err=self.window_err.cpu().numpy().copy())
             rec.update(robot_status=self.robot_status.cpu().numpy().copy(), pose0=self.pose0.cpu().numpy().copy(),
                        init_params=self.init_params.cpu().numpy().copy(), path_pts=self.path_pts.cpu().numpy().copy(),
                        goal_yaw=self.goal_yaw.cpu().numpy().copy(), people_proj=self.people_proj.cpu().numpy().copy(),
@@ -290,7 +305,8 @@ class BatchEpisode:
         #    trajectorizer's own motion model (x, y with the old heading, then the heading)
         s.select_command_device(B, T, self.rows, self.traj_n.data_ptr() if self.plan is not None else 0,
                                 self.plan_cmds.data_ptr(), self.res["status"].data_ptr(), self.res["cmds"].data_ptr(),
-                                self.cmd_vel.data_ptr(), self.cmd_source.data_ptr())
+                                self.cmd_vel.data_ptr(), self.cmd_source.data_ptr(),
+                                self.window_err.data_ptr() if self.plan_window is not None else 0)
         dt = prm.dt
         v, w, th = self.cmd_vel[:, 0], self.cmd_vel[:, 1], self.pose[:, 2]
         moved = torch.stack([self.pose[:, 0] + v * torch.cos(th) * dt, self.pose[:, 1] + v * torch.sin(th) * dt, th + w * dt], dim=1)
@@ -312,7 +328,7 @@ class BatchEpisode:
         self.gstream = stream if stream is not None else torch.cuda.Stream(device=self.dev)
         self.gstream.wait_stream(torch.cuda.current_stream(self.dev))
         self.solver.set_stream(self.gstream.cuda_stream)
-        state = ("pose", "speed", "persons", "mem_path", "mem_cmds", "mem_valid", "order") + (("plan_start",) if self.plan_window is not None else ())
+        state = ("pose", "speed", "persons", "mem_path", "mem_cmds", "mem_valid", "mem_length", "order") + (("plan_start",) if self.plan_window is not None else ())
         with torch.cuda.stream(self.gstream):
             saved = {k: getattr(self, k).clone() for k in state}
             ticks = self.ticks

@@ -67,13 +67,13 @@ def load_library():
     lib.smpc_format_to_optimize_batch.argtypes = [C.c_void_p, C.POINTER(SmpcFormatBatch), C.POINTER(SmpcFormatOut)]
     lib.smpc_format_to_optimize_batch.restype = C.c_int
     lib.smpc_memory_store_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.POINTER(SmpcMemoryBatch)]
+                                            C.POINTER(SmpcMemoryBatch), C.c_void_p]
     lib.smpc_memory_store_batch.restype = C.c_int
     lib.smpc_trajectorize_path_batch.argtypes = [C.c_void_p, C.POINTER(SmpcTrajectorizeBatch), C.POINTER(SmpcTrajectorizeOut)]
     lib.smpc_trajectorize_path_batch.restype = C.c_int
     lib.smpc_transform_global_plan_batch.argtypes = [C.c_void_p, C.POINTER(SmpcPlanWindowBatch), C.c_void_p, C.c_void_p, C.c_void_p]
     lib.smpc_transform_global_plan_batch.restype = C.c_int
-    lib.smpc_select_command_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 6
+    lib.smpc_select_command_batch.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7
     lib.smpc_select_command_batch.restype = C.c_int
     lib.smpc_stage_people_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.c_void_p]
     lib.smpc_stage_people_batch.restype = C.c_int
@@ -314,9 +314,10 @@ class BatchSolver:
                "smpc_people_to_status_batch")
         return out, has
 
-    def select_command(self, traj_n_poses, traj_cmds: np.ndarray, status: np.ndarray, cmds: np.ndarray):
+    def select_command(self, traj_n_poses, traj_cmds: np.ndarray, status: np.ndarray, cmds: np.ndarray, window_error=None):
         """The command computeVelocityCommands returns for B robots (fallbacks included): traj_cmds [B,rows,2],
-        status [B], cmds [B,T+1,2], traj_n_poses [B] or None. Returns (cmd_vel [B,2], source [B])."""
+        status [B], cmds [B,T+1,2], traj_n_poses [B] or None, window_error [B] (smpc_window_error of this cycle) or None.
+        Returns (cmd_vel [B,2], source [B])."""
         traj_cmds = np.ascontiguousarray(traj_cmds, np.float64)
         status = np.ascontiguousarray(status, np.int32)
         cmds = np.ascontiguousarray(cmds, np.float64)
@@ -324,31 +325,45 @@ class BatchSolver:
         T = cmds.shape[1] - 1
         n = None if traj_n_poses is None else np.ascontiguousarray(traj_n_poses, np.int32)
         out, src = np.zeros((B, 2)), np.zeros(B, np.int32)
+        we = None if window_error is None else np.ascontiguousarray(window_error, np.int32)
         _check(self.lib, self.lib.smpc_select_command_batch(self._h, B, T, rows, 0, None if n is None else n.ctypes.data,
                                                             traj_cmds.ctypes.data, status.ctypes.data, cmds.ctypes.data,
-                                                            out.ctypes.data, src.ctypes.data), "smpc_select_command_batch")
+                                                            out.ctypes.data, src.ctypes.data,
+                                                            None if we is None else we.ctypes.data), "smpc_select_command_batch")
         return out, src
 
-    def select_command_device(self, B, T, rows, traj_n_ptr, traj_cmds_ptr, status_ptr, cmds_ptr, cmd_vel_ptr, source_ptr):
+    def select_command_device(self, B, T, rows, traj_n_ptr, traj_cmds_ptr, status_ptr, cmds_ptr, cmd_vel_ptr, source_ptr,
+                              window_error_ptr=0):
         _check(self.lib, self.lib.smpc_select_command_batch(self._h, B, T, rows, 1, C.c_void_p(traj_n_ptr), C.c_void_p(traj_cmds_ptr),
                                                             C.c_void_p(status_ptr), C.c_void_p(cmds_ptr), C.c_void_p(cmd_vel_ptr),
-                                                            C.c_void_p(source_ptr)), "smpc_select_command_batch")
+                                                            C.c_void_p(source_ptr), C.c_void_p(window_error_ptr)),
+               "smpc_select_command_batch")
 
     # -- warm start / input formatting: format_to_optimize + TrajectoryMemory for B scenes -----
     def format_to_optimize(self, path: np.ndarray, cmds: np.ndarray, speed: np.ndarray, memory: dict,
-                           current_path_w: float = None, current_cmds_w: float = None):
-        """path [B,T+1,3] (x, y, yaw), cmds [B,T+1,2], speed [B,2]; memory = new_memory(B, T) (updated in place when a
-        record is empty). Returns dict(robot_status [B,T+1,6], pose0, init_params, path_pts, goal_yaw)."""
+                           current_path_w: float = None, current_cmds_w: float = None, n_poses=None, max_poses: int = 0,
+                           T: int = None):
+        """path [B,rows,3] (x, y, yaw), cmds [B,rows,2], speed [B,2]; memory = new_memory(B, T) (updated in place when a
+        record is empty). T: horizon (stride) of the outputs, default rows - 1. n_poses [B] + max_poses: horizons per
+        scene (smpc_format_batch.n_poses; the memory then needs its `length` array: new_memory(..., lengths=True)).
+        Returns dict(robot_status [B,T+1,6], pose0, init_params, path_pts, goal_yaw, T_scene)."""
         path = np.ascontiguousarray(path, np.float64)
         cmds = np.ascontiguousarray(cmds, np.float64)
         speed = np.ascontiguousarray(speed, np.float64)
-        B, Tp, _ = path.shape
-        T = Tp - 1
-        assert cmds.shape == (B, Tp, 2) and speed.shape == (B, 2)
+        B, rows, _ = path.shape
+        T = rows - 1 if T is None else int(T)
+        Tp = T + 1
+        assert cmds.shape == (B, rows, 2) and speed.shape == (B, 2) and rows >= Tp
         assert memory["prev_path"].shape == (B, Tp, 3) and memory["prev_cmds"].shape == (B, Tp, 2)
         CH, bl, nb, P, M, _ = self.params.dims(T, True)
         fb = SmpcFormatBatch()
-        fb.B, fb.T, fb.path_rows, fb.on_device = B, T, Tp, 0
+        fb.B, fb.T, fb.path_rows, fb.on_device = B, T, rows, 0
+        if n_poses is not None:
+            n_poses = np.ascontiguousarray(n_poses, np.int32)
+            assert n_poses.shape == (B,) and "length" in memory
+            fb.n_poses, fb.max_poses = n_poses.ctypes.data, int(max_poses)
+        if "length" in memory:
+            fb.memory.length = memory["length"].ctypes.data
         fb.time_step = float(self.params.dt)
         fb.current_path_w = float(self.params.current_path_weight if current_path_w is None else current_path_w)
         fb.current_cmds_w = float(self.params.current_cmds_weight if current_cmds_w is None else current_cmds_w)
@@ -357,7 +372,7 @@ class BatchSolver:
         fb.memory.prev_cmds = memory["prev_cmds"].ctypes.data
         fb.memory.valid = memory["valid"].ctypes.data
         out = {"robot_status": np.zeros((B, Tp, 6)), "pose0": np.zeros((B, 3)), "init_params": np.zeros((B, P)),
-               "path_pts": np.zeros((B, Tp, 2)), "goal_yaw": np.zeros(B)}
+               "path_pts": np.zeros((B, Tp, 2)), "goal_yaw": np.zeros(B), "T_scene": np.zeros(B, np.int32)}
         fo = SmpcFormatOut()
         for k, v in out.items():
             setattr(fo, k, v.ctypes.data)
@@ -366,12 +381,17 @@ class BatchSolver:
         return out
 
     @staticmethod
-    def new_memory(B: int, T: int):
-        """An empty TrajectoryMemory record per scene (host arrays)."""
-        return {"prev_path": np.zeros((B, T + 1, 3)), "prev_cmds": np.zeros((B, T + 1, 2)), "valid": np.zeros(B, np.int32)}
+    def new_memory(B: int, T: int, lengths: bool = False):
+        """An empty TrajectoryMemory record per scene (host arrays). lengths: with the per-record sizes that scenes with
+        horizons of their own need (smpc_memory_batch.length)."""
+        m = {"prev_path": np.zeros((B, T + 1, 3)), "prev_cmds": np.zeros((B, T + 1, 2)), "valid": np.zeros(B, np.int32)}
+        if lengths:
+            m["length"] = np.zeros((B, 2), np.int32)
+        return m
 
-    def memory_store(self, status: np.ndarray, path: np.ndarray, cmds: np.ndarray, memory: dict):
-        """The store at the end of Optimizer::optimize: usable solves (status != FAILURE) overwrite their record."""
+    def memory_store(self, status: np.ndarray, path: np.ndarray, cmds: np.ndarray, memory: dict, T_scene=None):
+        """The store at the end of Optimizer::optimize: usable solves (status != FAILURE) overwrite their record (the
+        first T_scene[b] + 1 rows when the scenes have horizons of their own)."""
         status = np.ascontiguousarray(status, np.int32)
         path = np.ascontiguousarray(path, np.float64)
         cmds = np.ascontiguousarray(cmds, np.float64)
@@ -379,17 +399,23 @@ class BatchSolver:
         mb = SmpcMemoryBatch()
         mb.prev_path, mb.prev_cmds, mb.valid = (memory["prev_path"].ctypes.data, memory["prev_cmds"].ctypes.data,
                                                 memory["valid"].ctypes.data)
+        if "length" in memory:
+            mb.length = memory["length"].ctypes.data
+        ts = None if T_scene is None else np.ascontiguousarray(T_scene, np.int32)
         _check(self.lib, self.lib.smpc_memory_store_batch(self._h, B, Tp - 1, 0, status.ctypes.data, path.ctypes.data,
-                                                          cmds.ctypes.data, C.byref(mb)), "smpc_memory_store_batch")
+                                                          cmds.ctypes.data, C.byref(mb), None if ts is None else ts.ctypes.data),
+               "smpc_memory_store_batch")
 
     def format_device(self, fb: SmpcFormatBatch, fo: SmpcFormatOut):
         assert fb.on_device == 1
         _check(self.lib, self.lib.smpc_format_to_optimize_batch(self._h, C.byref(fb), C.byref(fo)),
                "smpc_format_to_optimize_batch")
 
-    def memory_store_device(self, B: int, T: int, status_ptr: int, path_ptr: int, cmds_ptr: int, mb: SmpcMemoryBatch):
+    def memory_store_device(self, B: int, T: int, status_ptr: int, path_ptr: int, cmds_ptr: int, mb: SmpcMemoryBatch,
+                            T_scene_ptr: int = 0):
         _check(self.lib, self.lib.smpc_memory_store_batch(self._h, B, T, 1, C.c_void_p(status_ptr), C.c_void_p(path_ptr),
-                                                          C.c_void_p(cmds_ptr), C.byref(mb)), "smpc_memory_store_batch")
+                                                          C.c_void_p(cmds_ptr), C.byref(mb), C.c_void_p(T_scene_ptr)),
+               "smpc_memory_store_batch")
 
     def people_to_status_device(self, pb: SmpcPeopleBatch, out_ptr: int, has_people_ptr: int):
         assert pb.on_device == 1

@@ -221,7 +221,8 @@ def test_gpu_fov_filter_matches_pyref(fov):
 @pytest.mark.gpu
 def test_gpu_select_command_applies_the_reference_fallbacks():
     """computeVelocityCommands' returned command: optimised cmds[0], else the trajectorizer's first command
-    (src/social_mpc_controller.cpp:241-245), else 0.1 m/s straight (:180-189)."""
+    (src/social_mpc_controller.cpp:241-245), else 0.1 m/s straight (:180-189); nothing when transformGlobalPlan threw
+    (src/path_handler.cpp:44-47, 100-103). A path shorter than the batch's horizon is NOT a fallback case."""
     from nav2_social_mpc_controller_amd.params import OptimizerParams
     from nav2_social_mpc_controller_amd.solver import BatchSolver
     rng = np.random.default_rng(12)
@@ -229,8 +230,110 @@ def test_gpu_select_command_applies_the_reference_fallbacks():
     traj_cmds, cmds = rng.normal(size=(B, rows, 2)), rng.normal(size=(B, T + 1, 2))
     status = rng.integers(0, 3, size=B).astype(np.int32)
     n = rng.choice([0, 5, T + 1, rows], size=B).astype(np.int32)
-    got, src = BatchSolver(OptimizerParams.readme()).select_command(n, traj_cmds, status, cmds)
-    want_src = np.where(n <= 0, 2, np.where((n < T + 1) | (status == 2), 1, 0))
+    s = BatchSolver(OptimizerParams.readme())
+    got, src = s.select_command(n, traj_cmds, status, cmds)
+    want_src = np.where(n <= 0, 2, np.where(status == 2, 1, 0))
     want = np.where((want_src == 2)[:, None], np.array([0.1, 0.0]), np.where((want_src == 1)[:, None], traj_cmds[:, 0], cmds[:, 0]))
     assert np.array_equal(src, want_src) and np.array_equal(got, want)
-    assert set(want_src.tolist()) == {0, 1, 2}
+    assert set(want_src.tolist()) == {0, 1, 2} and ((n == 5) & (src == 0)).any()
+    werr = rng.choice([0, 0, 0, 1, 2], size=B).astype(np.int32)
+    got2, src2 = s.select_command(n, traj_cmds, status, cmds, window_error=werr)
+    assert np.array_equal(src2, np.where(werr != 0, 3, want_src))
+    assert np.array_equal(got2, np.where((werr != 0)[:, None], 0.0, want)) and (src2 == 3).any()
+
+
+def ragged_inputs(seed, B, rows, max_poses):
+    """paths of n poses each (n - 1 commands), n spread over 0, 1, 2 .. rows with the cut boundary well covered"""
+    rng = np.random.default_rng(seed)
+    path, cmds, speed = make_inputs(seed, B, rows - 1)
+    n = rng.integers(2, rows + 1, size=B)
+    n[:8] = [0, 1, 2, max_poses - 1, max_poses, max_poses + 1, rows, 3]
+    return path, cmds, speed, n.astype(np.int32)
+
+
+def test_pyref_with_path_lengths_matches_host_adapter(hostlib):
+    """Horizons per scene: the numpy statement against the transliterated Optimizer::format_to_optimize, scene by scene,
+    with incoming paths and memory records of every length (cut at round(max_time / dt), blending only while
+    i < previous_path.poses.size())."""
+    from oracle import pyref_format
+    max_time, dt = 1.5, 0.05
+    max_poses = int(np.round(np.float32(max_time) / np.float32(dt)))
+    T, rows, nb, B = max_poses - 1, max_poses + 1, 3, 64
+    path, cmds, speed, n = ragged_inputs(31, B, rows, max_poses)
+    prev_path, prev_cmds, _ = make_inputs(32, B, T)
+    rng = np.random.default_rng(33)
+    mem = pyref_format.new_memory(B, T, lengths=True)
+    plen = rng.integers(1, T + 2, size=B)
+    for s in range(B):
+        if s % 3:   # two thirds of the records hold a previous solution of some horizon (path and commands: same size)
+            mem["prev_path"][s, :plen[s]], mem["prev_cmds"][s, :plen[s]] = prev_path[s, :plen[s]], prev_cmds[s, :plen[s]]
+            mem["valid"][s], mem["length"][s] = 1, (plen[s], plen[s])
+    mem0 = {k: v.copy() for k, v in mem.items()}
+    out = pyref_format.format_to_optimize(path, cmds, speed, mem, 0.7, 0.4, dt, nb, n_poses=n, max_poses=max_poses, T=T)
+    checked = 0
+    for s in range(B):
+        if n[s] < 1:
+            assert out["T_scene"][s] == 0 and not out["robot_status"][s].any()
+            continue
+        have = mem0["valid"][s] != 0
+        L = int(mem0["length"][s, 0])
+        kept_s = max_poses - 1 if n[s] > max_poses else int(n[s])
+        if have and kept_s - 1 > L:
+            continue  # the reference indexes previous_cmds[i - 1] beyond its size for this combination (undefined behaviour)
+        # (the adapter takes n command slots; the reference reads cmds[i - 1] for i < kept only, :537-545)
+        ref = host_format(hostlib, path[s, :n[s]], cmds[s, :n[s]], mem0["prev_path"][s, :L] if have else None,
+                          mem0["prev_cmds"][s, :L] if have else None, speed[s], 0.7, 0.4, max_time, dt)
+        kept = out["T_scene"][s] + 1 if n[s] >= 2 else n[s]
+        assert ref.shape[0] == kept, (s, n[s], ref.shape)
+        assert np.max(np.abs(ref - out["robot_status"][s, :kept])) <= 1e-15, s
+        assert not out["robot_status"][s, kept:].any()
+        checked += 1
+    assert checked >= 40
+    assert out["T_scene"][:7].tolist() == [0, 0, 1, max_poses - 2, max_poses - 1, max_poses - 2, max_poses - 2]
+
+
+@pytest.mark.gpu
+def test_gpu_format_with_path_lengths_matches_pyref():
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    from oracle import pyref_format
+    prm = OptimizerParams.readme()
+    s = BatchSolver(prm)
+    max_poses = int(np.round(np.float32(prm.max_time) / np.float32(prm.time_step)))
+    T, rows, B = max_poses - 1, max_poses + 1, 400
+    nb = prm.dims(T, True)[2]
+    path, cmds, speed, n = ragged_inputs(41, B, rows, max_poses)
+    prev_path, prev_cmds, _ = make_inputs(42, B, T)
+    rng = np.random.default_rng(43)
+    mem = s.new_memory(B, T, lengths=True)
+    plen = rng.integers(1, T + 2, size=B)
+    for b in range(B):
+        if b % 3:
+            mem["prev_path"][b, :plen[b]], mem["prev_cmds"][b, :plen[b]] = prev_path[b, :plen[b]], prev_cmds[b, :plen[b]]
+            mem["valid"][b], mem["length"][b] = 1, (plen[b], plen[b])
+    mem_ref = {k: v.copy() for k, v in mem.items()}
+    got = s.format_to_optimize(path, cmds, speed, mem, 0.7, 0.4, n_poses=n, max_poses=max_poses, T=T)
+    exp = pyref_format.format_to_optimize(path, cmds, speed, mem_ref, 0.7, 0.4, prm.time_step, nb, n_poses=n,
+                                          max_poses=max_poses, T=T)
+    assert np.array_equal(got["T_scene"], exp["T_scene"])
+    for k in ("robot_status", "pose0", "init_params", "path_pts", "goal_yaw"):
+        err = np.abs(got[k] - exp[k])
+        if k in ("robot_status", "pose0", "goal_yaw"):
+            err = np.minimum(err, np.abs(err - 2 * np.pi))
+        assert np.max(err) <= 1e-13, k
+    for k in mem:
+        assert np.array_equal(mem[k], mem_ref[k]), k
+    # the store of a solve with those horizons, then a second format against records of mixed sizes
+    status = rng.integers(0, 3, size=B).astype(np.int32)
+    res_path, res_cmds, _ = make_inputs(44, B, T)
+    s.memory_store(status, res_path, res_cmds, mem, T_scene=np.maximum(got["T_scene"], 1))
+    pyref_format.memory_store(status, res_path, res_cmds, mem_ref, T_scene=np.maximum(exp["T_scene"], 1))
+    for k in mem:
+        assert np.array_equal(mem[k], mem_ref[k]), k
+    path2, cmds2, speed2, n2 = ragged_inputs(45, B, rows, max_poses)
+    got2 = s.format_to_optimize(path2, cmds2, speed2, mem, 0.7, 0.4, n_poses=n2, max_poses=max_poses, T=T)
+    exp2 = pyref_format.format_to_optimize(path2, cmds2, speed2, mem_ref, 0.7, 0.4, prm.time_step, nb, n_poses=n2,
+                                           max_poses=max_poses, T=T)
+    assert np.array_equal(got2["T_scene"], exp2["T_scene"])
+    err = np.abs(got2["robot_status"] - exp2["robot_status"])
+    assert np.max(np.minimum(err, np.abs(err - 2 * np.pi))) <= 1e-13

@@ -36,6 +36,7 @@ def test_pyref_statements_reproduce_the_vectors(G):
     o1 = pyref_format.format_to_optimize(G["f2_path"], G["f2_cmds"], G["f2_speed"], mem, 1.0, 0.5, 0.05, 3)
     pyref_format.memory_store(G["f2_res_status"], G["f2_res_path"], G["f2_res_cmds"], mem)
     o2 = pyref_format.format_to_optimize(G["f2_path2"], G["f2_cmds2"], G["f2_speed2"], mem, 0.7, 0.3, 0.05, 3)
+    assert (o1.pop("T_scene") == Tp - 1).all() and (o2.pop("T_scene") == Tp - 1).all()   # fixed horizon (no n_poses)
     for k in o1:
         assert np.max(np.abs(o1[k] - G["f2_call1_" + k])) <= 1e-14 and np.max(np.abs(o2[k] - G["f2_call2_" + k])) <= 1e-14
     for k in mem:
@@ -76,6 +77,7 @@ def test_gpu_format_chain_reproduces_the_vectors(G, solver):
     solver.memory_store(G["f2_res_status"], G["f2_res_path"], G["f2_res_cmds"], mem)
     o2 = solver.format_to_optimize(G["f2_path2"], G["f2_cmds2"], G["f2_speed2"], mem, 0.7, 0.3)
     for o, tag in ((o1, "f2_call1_"), (o2, "f2_call2_")):
+        assert (o.pop("T_scene") == Tp - 1).all()
         for k in o:
             assert yaw_close(o[k], G[tag + k], 1e-13), (tag, k)
     for k in mem:
