@@ -57,6 +57,7 @@ struct KParams {
   const double* people_rec;  // [B][N][T][4]  px, py, vx, vy of people_proj[t + 1][a]
   const double* people_aux;  // [B][T][2]     bit mask of valid agents (u64 bits), agent-angle target (kNoTarget: none)
   const int32_t* order;      // [B] queue order of the solve kernel (null: index order)
+  int prio_step;             // > 0: a wave whose oldest scene has made n sweeps runs at wave priority min(n / prio_step, 3)
   double* stage_rec;         // staging kernel outputs (same layouts)
   double* stage_aux;
   unsigned long long* stamps;  // diagnostic builds only (SMPC_STAMPS): per-wave cycle sums per phase, [grid][8]
@@ -77,6 +78,11 @@ struct KParams {
 // instructions per value). The buffer (W rows of kGramChunk + 1 doubles) lies over the sweep's own temporaries — the
 // cos / sin block and the scans are dead once the sensitivities are formed — plus a tail of its own; outside the
 // sweep the same area holds the temporaries of the LM algebra.
+constexpr int kSensInRegsMaxBlocks = 6;  // K1 keeps a lane's sensitivities in registers up to this many parameter blocks
+// doubles of wave-shared LDS of the K1 kernel: two row staging blocks per slot, and the parked sensitivities
+__host__ __device__ constexpr int eval_extra_doubles(int T, int P, int W) {
+  return (64 / W) * (2 * T * P) + (P / 2 > kSensInRegsMaxBlocks ? (64 / W) * (5 * (P / 2) * W) : 0);
+}
 constexpr int kGramChunk = 16;
 __host__ __device__ constexpr int gram_red_doubles(int W) { return W * (kGramChunk + 1); }
 // doubles of wave-shared LDS behind the per-slot blocks of the solve kernel: the feasibility rows of every slot
@@ -899,6 +905,19 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     }
   };
   if (kRows) compute_sensitivities();
+  // K1 with seven or more parameter blocks: the 5 NB sensitivities of a lane (100 registers at NB = 10) are parked in LDS
+  // behind the row staging blocks, lane index fastest, and read back entry by entry while the rows are formed — with
+  // them in registers the kernel needed 256 VGPRs plus up to 110 AGPR copies
+  constexpr bool kSensInLds = kRows && NB > kSensInRegsMaxBlocks;
+  double* sens_lds = c.wave_lds + (kWave / W) * (2 * T * P) + c.slot * (5 * NB * W) + sl;
+  if (kSensInLds) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      sens_lds[(0 * NB + q) * W] = Sxv[q]; sens_lds[(1 * NB + q) * W] = Syv[q]; sens_lds[(2 * NB + q) * W] = Sxw[q];
+      sens_lds[(3 * NB + q) * W] = Syw[q]; sens_lds[(4 * NB + q) * W] = Sthw[q];
+    }
+    wave_lds_fence();
+  }
 
   SMPC_STAMP(c, 4);
   // ---- per-step critics: residual r and its state-space gradient (gx, gy, gth; gv = direct derivative with respect
@@ -925,50 +944,48 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
 #pragma unroll
     for (int q = 0; q < Q; ++q) gcol[q] = 0.0;
   }
-  auto push = [&](const double (&row)[P], double r, bool live) {  // kRows only
-    const double rl = live ? r : 0.0;
-#pragma unroll
-    for (int q = 0; q < P; ++q) gcol[q] = fma(live ? row[q] : 0.0, rl, gcol[q]);
-    gcol[P] = fma(rl, rl, gcol[P]);
-  };
+  // One row of the Jacobian = gradient x M, formed two entries (one parameter block) at a time: each pair goes to its
+  // destination and into the last Gram column at once, so no whole row is ever held in registers (with ten parameter
+  // blocks a row is 40 registers on top of the 100 of the sensitivities).
   auto emit = [&](int local, bool live, bool slot_on, double r, double gx, double gy, double gth, double gv) {  // kRows only
-    double row[P];
+    const double rl = live ? r : 0.0;
+    double* blk = stage + (local & 1) * (T * P);
+    const int rowi = row_base + local;
+    const bool to_lds = critic_major && sl < T && slot_on;   // every row of the block, the all-zero rows of steps beyond
+                                                             // the scene's horizon included
+    const bool to_mem = !critic_major && live && out_J;
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      row[2 * q] = gx * Sxv[q] + gy * Syv[q] + ((q == myb) ? gv : 0.0);
-      row[2 * q + 1] = gx * Sxw[q] + gy * Syw[q] + gth * Sthw[q];
-    }
-    if (critic_major) {
-      // Row (critic `local`, step sl) lives at index local * T + sl: the T rows of one critic are one contiguous
-      // block of T * P doubles. They pass through LDS so that every store instruction writes whole runs of
+      const double sxv = kSensInLds ? sens_lds[(0 * NB + q) * W] : Sxv[q], syv = kSensInLds ? sens_lds[(1 * NB + q) * W] : Syv[q];
+      const double sxw = kSensInLds ? sens_lds[(2 * NB + q) * W] : Sxw[q], syw = kSensInLds ? sens_lds[(3 * NB + q) * W] : Syw[q];
+      const double sthw = kSensInLds ? sens_lds[(4 * NB + q) * W] : Sthw[q];
+      double e0 = gx * sxv + gy * syv + ((q == myb) ? gv : 0.0);
+      double e1 = gx * sxw + gy * syw + gth * sthw;
+      e0 = live ? e0 : 0.0; e1 = live ? e1 : 0.0;
+      gcol[2 * q] = fma(e0, rl, gcol[2 * q]);
+      gcol[2 * q + 1] = fma(e1, rl, gcol[2 * q + 1]);
+      v2d pr = {e0, e1};
+      // critic-major: row (critic `local`, step sl) lives at index local * T + sl, the T rows of one critic are one
+      // contiguous block of T * P doubles. They pass through LDS so that every store instruction writes whole runs of
       // consecutive 16-byte pieces (lane-strided 48-byte rows touch 64 different lines per instruction and leave
       // partially written lines behind: measured 1.49 x write amplification in round 1).
-      double* blk = stage + (local & 1) * (T * P);
-      if (sl < T && slot_on) {  // every row of the block, the all-zero rows of steps beyond the scene's horizon included
-#pragma unroll
-        for (int q = 0; q < P; q += 2) {
-          v2d pr = {live ? row[q] : 0.0, live ? row[q + 1] : 0.0};
-          reinterpret_cast<v2d*>(blk + sl * P)[q >> 1] = pr;
-        }
-      }
+      if (to_lds) reinterpret_cast<v2d*>(blk + sl * P)[q] = pr;
+      if (to_mem) reinterpret_cast<v2d*>(out_J + (size_t)rowi * P)[q] = pr;
+    }
+    gcol[P] = fma(rl, rl, gcol[P]);
+    if (critic_major) {
       wave_lds_fence();
       if (out_J && slot_on) {
         v2d* dst = reinterpret_cast<v2d*>(out_J + (size_t)local * T * P);
         const v2d* src = reinterpret_cast<const v2d*>(blk);
         for (int i = sl; i < T * NB; i += W) dst[i] = src[i];
       }
-      if (out_r && sl < T && slot_on) out_r[local * T + sl] = live ? r : 0.0;
+      if (out_r && sl < T && slot_on) out_r[local * T + sl] = rl;
       // no second fence: the next critic writes the other block, and the one after that comes behind this
       // critic's reads in program order with a fence in between
-    } else if (live) {
-      const int rowi = row_base + local;
-      if (out_r) out_r[rowi] = r;
-      if (out_J) {
-#pragma unroll
-        for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
-      }
+    } else if (live && out_r) {
+      out_r[rowi] = r;
     }
-    push(row, r, live);
   };
   if (__any(people)) {
     const bool live = lane_live && people;
@@ -1102,7 +1119,12 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
           for (int q = 0; q < P; ++q) out_J[(size_t)rowi * P + q] = row[q];
         }
       }
-      push(row, r, live);
+      {
+        const double rl = live ? r : 0.0;
+#pragma unroll
+        for (int q = 0; q < P; ++q) gcol[q] = fma(live ? row[q] : 0.0, rl, gcol[q]);
+        gcol[P] = fma(rl, rl, gcol[P]);
+      }
     }
 #pragma unroll
     for (int a = 0; a < Q; ++a) {

@@ -282,7 +282,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   KernelFn fn = pick(k.nb, W, eval, k.T_scene != nullptr);
   const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve);
   // behind the slot blocks: the MFMA row / result tiles (solve) or the two row staging blocks per slot (K1)
-  const size_t extra = eval ? (size_t)S * 2 * k.T * k.P : (size_t)smpc::wave_extra_doubles(k.P, W);
+  const size_t extra = eval ? (size_t)smpc::eval_extra_doubles(k.T, k.P, W) : (size_t)smpc::wave_extra_doubles(k.P, W);
   const size_t shmem = ((size_t)S * L.total + extra) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
   if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -309,6 +309,8 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     const int two_per_simd = lone_per_cu * h->num_cu < resident ? lone_per_cu * h->num_cu : resident;
     if (grid > two_per_simd) grid = (grid >= 4 * resident) ? resident : two_per_simd;
     k.queue = h->queue;
+    k.prio_step = 0;
+    if (const char* v = std::getenv("SMPC_PRIO_STEP")) { const int c = std::atoi(v); if (c >= 1) k.prio_step = c; }  // experiment knob
     SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));
   }
 #ifdef SMPC_STAMPS

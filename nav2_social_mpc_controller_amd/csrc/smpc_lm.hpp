@@ -591,6 +591,19 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
     }
     if (__all(R.phase == PH_IDLE)) break;
     SMPC_STAMP(c, 0);  // fetch + load_scene
+    if (k.prio_step > 0) {
+      // Attained-service priority: the launch ends when its longest scene does, and a scene's sweeps are a dependent
+      // chain — so the longer a scene has been running, the more of the SIMD's issue slots its wave gets against the
+      // younger waves beside it (which, having made few sweeps, most likely hold short scenes: lengths 11..146).
+      const int mine = (R.phase == PH_IDLE) ? 0 : R.evals;
+      int age = __builtin_amdgcn_readfirstlane(mine);
+      if (S == 2) age = max(age, __builtin_amdgcn_readlane(mine, 32));
+      const int step = k.prio_step;
+      if (age >= 3 * step) __builtin_amdgcn_s_setprio(3);
+      else if (age >= 2 * step) __builtin_amdgcn_s_setprio(2);
+      else if (age >= step) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
     park();

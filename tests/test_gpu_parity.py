@@ -241,6 +241,59 @@ def test_full_size_properties_cfg3(Solver):
     assert np.allclose(ev["cost"], r2["initial_cost"], rtol=1e-12)
 
 
+FULL_SIZE_SHAPES = {
+    # BASELINE configs at the size they are stated at (per GPU): the one-scene-per-wave shapes (T = 38) and cfg2
+    "cfg5_n16_h30_t38": (README.replace(control_horizon=30, max_time=2.0), dict(B=8192, N=16, seed=0x5EED0001), 512),
+    "params_yaml_n3_t38": (OptimizerParams.params_yaml(), dict(B=8192, N=3, seed=0x5EED0001), 512),
+    "cfg2_n4_b1024": (README, dict(B=1024, N=4, seed=0x5EED0001), 1024),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE_SHAPES))
+def test_full_size_properties_other_shapes(Solver, oracle, name):
+    """The properties of test_full_size_properties_cfg3 on the other BASELINE shapes at full size, plus the oracle on a
+    sample of the batch (the first `sample` scenes)."""
+    prm, kw, sample = FULL_SIZE_SHAPES[name]
+    sc = make_scenes(prm, **kw)
+    B, T = sc.B, sc.T
+    s = Solver(prm)
+    a = s.solve(sc)
+    b = s.solve(sc)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), f"non-deterministic output {k}"
+    CH, bl, nb, P, M, nbnd = prm.dims(T)
+    assert np.all(a["status"] != 2)
+    assert np.all(a["final_cost"] <= a["initial_cost"] * (1 + 1e-12))
+    assert np.all((a["iterations"] >= 0) & (a["iterations"] <= prm.max_iterations))
+    v, w = a["params"][:, 0:2 * nbnd:2], a["params"][:, 1:2 * nbnd:2]      # the bounded blocks (src/optimizer.cpp:373-379)
+    assert v.min() >= prm.v_min and v.max() <= prm.v_max and w.min() >= prm.w_min and w.max() <= prm.w_max
+    for i in range(T + 1):                                                              # a12 expansion
+        blk = i // bl if i < CH else (CH - 1) // bl
+        assert np.array_equal(a["cmds"][:, i, 0], a["params"][:, 2 * blk])
+        assert np.array_equal(a["cmds"][:, i, 1], a["params"][:, 2 * blk + 1])
+    stride = max(1, B // 512)
+    sc2 = sc.select(np.arange(0, B, stride))
+    x0 = np.clip(sc2.init_params, [prm.v_min, prm.w_min] * nbnd + [-np.inf, -np.inf] * (nb - nbnd),
+                 [prm.v_max, prm.w_max] * nbnd + [np.inf, np.inf] * (nb - nbnd))
+    ev = s.evaluate(sc2, x0)
+    assert np.allclose(ev["cost"], a["initial_cost"][::stride], rtol=1e-12)
+    # the oracle on a sample: every firm, well-conditioned scene within the tolerance, same status and iteration count
+    sub = sc.select(np.arange(sample))
+    rz = oracle.solve(prm, sub, nthreads=16, theta_zero_convention=True)
+    stable = well_conditioned(oracle, prm, sub, rz, nthreads=16, theta_zero_convention=True)
+    firm = (rz["marginal_decisions"] == 0) & stable
+    assert stable.mean() >= 0.97 and firm.mean() >= 0.9, (float(stable.mean()), float(firm.mean()))
+    err = cmd_err(a["cmds"][:sample], rz["cmds"])
+    assert np.max(err[firm]) <= CMD_TOL, float(np.max(err[firm]))
+    assert np.array_equal(a["status"][:sample][firm], rz["status"][firm])
+    assert np.array_equal(a["iterations"][:sample][firm], rz["iterations"][firm])
+    moved = ~firm & (err > CMD_TOL)
+    assert moved.mean() <= 0.03
+    if moved.any():
+        worse = (a["final_cost"][:sample][moved] - rz["final_cost"][moved]) / rz["final_cost"][moved]
+        assert np.all(worse <= 10 * prm.fn_tol), worse
+
+
 def test_edge_cases(Solver, oracle):
     prm = README
     s = Solver(prm)
