@@ -112,345 +112,16 @@ template <typename T> inline T MaxOf();
 template <> inline double MaxOf<double>() { return std::numeric_limits<double>::max(); }
 template <> inline Jet MaxOf<Jet>() { return Jet(std::numeric_limits<double>::max()); }
 
-template <typename T> struct Vec2 { T x, y; };
-template <typename T> inline T SquaredNorm(const Vec2<T>& p) { return p.x * p.x + p.y * p.y; }
-template <typename T> inline T Norm(const Vec2<T>& p) { return Sqrt(SquaredNorm(p)); }
-// Eigen's normalized(): z = squaredNorm(); z > 0 ? v / sqrt(z) : v.
-template <typename T> inline Vec2<T> Normalized(const Vec2<T>& p) {
-  T z = SquaredNorm(p);
-  if (z > 0.0) { T n = Sqrt(z); return Vec2<T>{p.x / n, p.y / n}; }
-  return p;
-}
+#include "smpc_functors.inc"  // the functors, templated on the scalar type (shared with oracle/ceres_harness.cpp)
 
-// ------------------------------------------------------------------------------------------------
-// Scene view (one scene of the batch) and derived dimensions.
-// ------------------------------------------------------------------------------------------------
-struct Dims {
-  int T, N, CH, bl, nb, P, M, nbounded;
-  bool has_people;
-};
-
-struct Scene {
-  Dims d;
-  double dt;
-  double x0, y0, yaw0;
-  const double* path_pts;  // [T+1][2]
-  double goal_yaw;
-  const double* people;  // [T+1][6][N]
-  const uint8_t* costmap;
-  int size_x, size_y;
-  double origin_x, origin_y, resolution;
-  const smpc_params* prm;
-  double person(int k, int field, int a) const { return people[(static_cast<size_t>(k) * 6 + field) * d.N + a]; }
-};
-
-Dims MakeDims(const smpc_params& p, int T, int N, bool has_people) {
-  Dims d;
-  d.T = T; d.N = N; d.has_people = has_people;
-  // src/optimizer.cpp:248-249
-  d.CH = std::min(p.control_horizon, T);
-  d.bl = std::min(p.parameter_block_length, d.CH);
-  d.nb = (d.CH - 1) / d.bl + 1;
-  d.P = 2 * d.nb;
-  d.nbounded = d.CH / d.bl;                                    // :373
-  const int nfeas = std::max(0, std::min(d.CH / d.bl, T) - 1);  // :364, i in 1..min(CH/bl, T)-1
-  d.M = (has_people ? 8 : 5) * T + nfeas;
-  return d;
-}
-
-// ------------------------------------------------------------------------------------------------
-// a1  computeUpdatedStateRedux  (include/nav2_social_mpc_controller/update_state.hpp:37-63)
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-inline void Rollout(const Scene& s, T const* const* parameters, int i, T* xo, T* yo, T* tho) {
-  T x = T(s.x0), y = T(s.y0), theta = T(s.yaw0);
-  const int CH = s.d.CH, bl = s.d.bl;
-  for (int j = 0; j <= i; ++j) {                       // :46  (j <= i: pose after i+1 steps)
-    const int b = (j < CH) ? j / bl : (CH - 1) / bl;   // :48-59
-    x += parameters[b][0] * Cos(theta) * s.dt;
-    y += parameters[b][0] * Sin(theta) * s.dt;
-    theta += parameters[b][1] * s.dt;
-  }
-  *xo = x; *yo = y; *tho = theta;
-}
-
-// critics/social_work_cost_function.hpp:39-46
-template <typename T> inline T WrapToPi(T angle) {
-  while (angle > M_PI) angle -= 2.0 * M_PI;
-  while (angle <= -M_PI) angle += 2.0 * M_PI;
-  return angle;
-}
-
-template <typename T> struct Agent6 { T x, y, yaw, t, lv, av; };
-
-// Diagnostic only: number of social-force evaluations whose sign(theta) (:210) was decided by last-bit rounding
-// noise: both velocities equal (velDiff == 0 exactly, so theta is mathematically 0) yet theta came out non-zero
-// (and the force term it flips is not negligible, |fa| > 1e-10).
-// The reference's own result then depends on its libm / compiler; parity tests report and set such scenes aside.
-thread_local long g_sign_noise_events = 0;
-// Test-infrastructure option (smpc_oracle_set_option): 0 = reference-literal (default); 1 = when both velocities
-// are exactly equal take theta == 0 exactly instead of the libm-noise value. This is the convention the HIP path
-// uses (csrc/smpc_device.hpp social_force); with it the oracle is a noise-free checker for every scene.
-int g_opt_theta_zero_when_equal_velocities = 0;
-// Diagnostic only: number of accept / terminate / Armijo decisions of a solve whose margin was below 1e-12 of the
-// cost, i.e. inside the rounding noise of summing ~300 squared residuals in a different order (SURVEY Appendix A.12:
-// "near an accept/reject or tolerance threshold a 1-ulp difference can flip a branch"). Parity tests report and set
-// such scenes aside; the reference's own path is not reproducible across builds there either.
-thread_local long g_marginal_decisions = 0;
-inline void NoteDecision(double lhs, double rhs, double cost_scale) {
-  if (std::fabs(lhs - rhs) <= 1e-12 * std::fabs(cost_scale)) ++g_marginal_decisions;
-}
-inline void ZeroValue(double& x) { x = 0.0; }
+// the dual-number overloads the functors find by argument-dependent lookup
 inline void ZeroValue(Jet& x) { x.a = 0.0; }
-
-// a3  computeSocialForce (critics/social_work_cost_function.hpp:164-228); constants src/critics/social_work_cost_function.cpp:38-43
-template <typename T>
-Vec2<T> SocialForce(const Agent6<T>& me, const Agent6<T>* agents, int n_agents) {
-  const double lambda = 2.0, gamma = 0.35, nPrime = 3.0, n = 2.0, forceFactor = 2.1;
-  Vec2<T> force{T(0.0), T(0.0)};
-  Vec2<T> mePos{me.x, me.y};
-  Vec2<T> meVel{me.lv * Cos(me.yaw), me.lv * Sin(me.yaw)};                                 // :170-171
-  for (int i = 0; i < n_agents; ++i) {
-    if (agents[i].t == -1.0) continue;                                                      // :175
-    Vec2<T> diff{mePos.x - agents[i].x, mePos.y - agents[i].y};                             // :179-180
-    if (Norm(diff) < 1e-6) diff = Vec2<T>{T(1e-6), T(0.0)};                                 // :181-184
-    Vec2<T> diffDirection = Normalized(diff);                                               // :185
-    Vec2<T> aVel{agents[i].lv * Cos(agents[i].yaw), agents[i].lv * Sin(agents[i].yaw)};     // :187-188
-    Vec2<T> velDiff{meVel.x - aVel.x, meVel.y - aVel.y};                                    // :189-190
-    Vec2<T> iv{T(lambda) * velDiff.x + diffDirection.x, T(lambda) * velDiff.y + diffDirection.y};  // :191-192
-    T interactionLength = Norm(iv);                                                         // :194
-    Vec2<T> idir{iv.x / interactionLength, iv.y / interactionLength};                       // :195-196
-    T theta = WrapToPi(Atan2(diffDirection.y, diffDirection.x) - Atan2(idir.y, idir.x));    // :198-200
-    const bool sign_is_noise = Value(velDiff.x) == 0.0 && Value(velDiff.y) == 0.0 && Value(theta) != 0.0;
-    if (sign_is_noise && g_opt_theta_zero_when_equal_velocities) ZeroValue(theta);
-    T B = T(gamma) * interactionLength;                                                     // :203
-    T fv = -Exp(-Norm(diff) / B - (T(nPrime) * B * theta) * (T(nPrime) * B * theta));       // :205-207
-    T sign = (theta > 0.0) ? T(1.0) : T(-1.0);                                              // :210
-    T fa = -sign * Exp(-Norm(diff) / B - (T(n) * B * theta) * (T(n) * B * theta));          // :212-215
-    if (sign_is_noise && std::fabs(Value(fa)) > 1e-10) ++g_sign_noise_events;  // diagnostic only
-    Vec2<T> forceVelocity{fv * idir.x, fv * idir.y};                                        // :218
-    Vec2<T> leftNormal{-idir.y, idir.x};                                                    // :220
-    Vec2<T> forceAngle{fa * leftNormal.x, fa * leftNormal.y};                               // :222
-    force.x += T(forceFactor) * (forceVelocity.x + forceAngle.x);                           // :224
-    force.y += T(forceFactor) * (forceVelocity.y + forceAngle.y);
-  }
-  return force;
-}
-
-template <typename T>
-inline void RobotState(const Scene& s, T const* const* parameters, int i, Agent6<T>* robot) {
-  Rollout(s, parameters, i, &robot->x, &robot->y, &robot->yaw);
-  robot->t = T((i + 1) * 1.0 * s.dt);  // counter_step = counter * time_step, src/optimizer.cpp:253,262
-  const int b = (i < s.d.CH) ? i / s.d.bl : (s.d.CH - 1) / s.d.bl;  // social_work:114-123
-  robot->lv = parameters[b][0];
-  robot->av = parameters[b][1];
-}
-
-template <typename T>
-inline void LoadAgents(const Scene& s, int k, std::vector<Agent6<T>>* agents) {
-  agents->resize(s.d.N);
-  for (int a = 0; a < s.d.N; ++a) {
-    (*agents)[a] = Agent6<T>{T(s.person(k, 0, a)), T(s.person(k, 1, a)), T(s.person(k, 2, a)),
-                             T(s.person(k, 3, a)), T(s.person(k, 4, a)), T(s.person(k, 5, a))};
-  }
-}
-
-// a3  SocialWorkCost::operator() (critics/social_work_cost_function.hpp:102-150)
-template <typename T>
-T SocialWorkResidual(const Scene& s, T const* const* parameters, int i) {
-  std::vector<Agent6<T>> agents;
-  LoadAgents(s, i + 1, &agents);  // people_proj[i + 1], src/optimizer.cpp:265
-  Agent6<T> robot;
-  RobotState(s, parameters, i, &robot);
-  Vec2<T> robot_sf = SocialForce(robot, agents.data(), s.d.N);                  // :125
-  T wr = SquaredNorm(robot_sf);                                                  // :126
-  T wp = T(0.0);
-  // robot_agent: column 0 = robot, remaining columns invalid (:130-136); only column 0 contributes.
-  for (int a = 0; a < s.d.N; ++a) {                                              // :137 every column, valid or not
-    Vec2<T> agent_sf = SocialForce(agents[a], &robot, 1);                        // :141
-    wp += SquaredNorm(agent_sf);                                                 // :142
-  }
-  T total = wr + wp + T(1e-6);                                                   // :144
-  return T(s.prm->socialwork_w) * total;                                         // :147
-}
-
-// a4  ProxemicsCost (critics/proxemics_cost_function.hpp:83-110,125-151); alpha, d0: src/critics/proxemics_cost_function.cpp:37-38
-template <typename T>
-T ProxemicsResidual(const Scene& s, T const* const* parameters, int i) {
-  const double alpha = 3.0, d0 = 0.5;
-  std::vector<Agent6<T>> agents;
-  LoadAgents(s, i + 1, &agents);
-  Agent6<T> robot;
-  RobotState(s, parameters, i, &robot);
-  T min_distance = MaxOf<T>();                                                   // :127
-  for (int a = 0; a < s.d.N; ++a) {
-    if (agents[a].t == -1.0) continue;                                           // :134
-    Vec2<T> diff{robot.x - agents[a].x, robot.y - agents[a].y};
-    T sq = SquaredNorm(diff);                                                    // :140 (the <1e-6 branch :141-144 has no effect)
-    if (sq < min_distance) min_distance = sq;                                    // std::min(min_distance, sq) keeps the whole dual
-  }
-  T cost = T(alpha) * Exp(-min_distance / (T(d0) * T(d0)));                      // :147-148
-  return T(s.prm->proxemics_w) * cost;                                           // :107
-}
-
-// a7  AgentAngleCost (critics/agent_angle_cost_function.hpp:125-195); safe distance^2: src/critics/agent_angle_cost_function.cpp:31
-template <typename T>
-T AgentAngleResidual(const Scene& s, T const* const* parameters, int i) {
-  T x, y, th;
-  Rollout(s, parameters, i, &x, &y, &th);
-  int closest = -1;
-  double closest_d2 = std::numeric_limits<double>::infinity();
-  for (int a = 0; a < s.d.N; ++a) {                                              // :130-141
-    const double dx = s.person(i + 1, 0, a) - s.x0;
-    const double dy = s.person(i + 1, 1, a) - s.y0;
-    const double d2 = dx * dx + dy * dy;
-    if (d2 < closest_d2 && s.person(i + 1, 4, a) > 0.05) { closest_d2 = d2; closest = a; }
-  }
-  if (closest < 0 || closest_d2 > 4.0) return T(0.0);                            // :142-146
-  const double ax = s.person(i + 1, 0, closest), ay = s.person(i + 1, 1, closest), ayaw = s.person(i + 1, 2, closest);
-  T agent_angle_initial = Atan2(T(ay - s.y0), T(ax - s.x0));                     // :151
-  T robot_yaw = T(s.yaw0);                                                       // :152
-  T agent_heading_diff = Atan2(Sin(T(ayaw) - robot_yaw), Cos(T(ayaw) - robot_yaw));  // :154
-  auto wrapAngle = [](const T& angle) -> T { return Atan2(Sin(angle), Cos(angle)); };  // :156
-  const double kThreshold = M_PI / 6.0, kUpper = 5 * M_PI / 6.0;                 // :160-161
-  const double steering_right = -(M_PI / 6.0), steering_left = M_PI / 6.0;       // :162-163
-  T angular_diff;
-  if (agent_heading_diff <= -kUpper || agent_heading_diff >= kThreshold) {       // :166
-    if (wrapAngle(agent_angle_initial - robot_yaw) < 0.0) return T(0.0);         // :168-172
-    angular_diff = wrapAngle(th - (robot_yaw + steering_right));                 // :175
-  } else {
-    if (wrapAngle(agent_angle_initial - robot_yaw) > 0.0) return T(0.0);         // :181-185
-    angular_diff = wrapAngle(th - (robot_yaw + steering_left));                  // :188
-  }
-  T cost = angular_diff * angular_diff;                                          // :191
-  return s.prm->agent_angle_w * cost;                                            // :192
-}
-
-// a6  VelocityCost (critics/velocity_cost_function.hpp:89-99)
-template <typename T>
-T VelocityResidual(const Scene& s, T const* const* parameters, int i) {
-  if (i < s.d.CH) {
-    T diff = T(s.prm->desired_linear_vel) - parameters[i / s.d.bl][0];
-    return T(s.prm->velocity_w) * diff * diff;
-  }
-  return T(0.0);
-}
-
-// a8  GoalAlignCost (critics/goal_align_cost_function.hpp:100-116)
-template <typename T>
-T GoalAlignResidual(const Scene& s, T const* const* parameters, int i) {
-  T x, y, th;
-  Rollout(s, parameters, i, &x, &y, &th);
-  T turning = Atan2(Sin(s.goal_yaw - th), Cos(s.goal_yaw - th));                 // :111-112
-  return T(s.prm->goal_align_w) * turning * turning;                             // :113
-}
-
-// a2  DistanceCost (critics/distance_cost_function.hpp:117-132)
-template <typename T>
-T DistanceResidual(const Scene& s, T const* const* parameters, int i, double weight, double px, double py) {
-  T x, y, th;
-  Rollout(s, parameters, i, &x, &y, &th);
-  Vec2<T> d{x - T(px), y - T(py)};
-  return T(weight) * SquaredNorm(d) * SquaredNorm(d);                            // :129
-}
-
-// a5  Grid2D<u_char> clamp-to-edge + BiCubicInterpolator (Ceres public semantics).
-inline double GridValue(const Scene& s, int r, int c) {
-  r = std::min(std::max(r, 0), s.size_y - 1);
-  c = std::min(std::max(c, 0), s.size_x - 1);
-  return static_cast<double>(s.costmap[static_cast<size_t>(r) * s.size_x + c]);
-}
-// Cubic Hermite (Catmull-Rom) through p0..p3 at x in [0,1] measured from p1: value and d/dx.
-inline void CubicHermite(double p0, double p1, double p2, double p3, double x, double* f, double* dfdx) {
-  const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
-  const double b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
-  const double c = 0.5 * (-p0 + p2);
-  const double d = p1;
-  if (f) *f = d + x * (c + x * (b + x * a));
-  if (dfdx) *dfdx = c + x * (2.0 * b + 3.0 * a * x);
-}
-inline void BiCubic(const Scene& s, double r, double c, double* f, double* dfdr, double* dfdc) {
-  const int row = static_cast<int>(std::floor(r));
-  const int col = static_cast<int>(std::floor(c));
-  double f0, f1, f2, f3, df0dc, df1dc, df2dc, df3dc;
-  CubicHermite(GridValue(s, row - 1, col - 1), GridValue(s, row - 1, col), GridValue(s, row - 1, col + 1), GridValue(s, row - 1, col + 2), c - col, &f0, &df0dc);
-  CubicHermite(GridValue(s, row, col - 1), GridValue(s, row, col), GridValue(s, row, col + 1), GridValue(s, row, col + 2), c - col, &f1, &df1dc);
-  CubicHermite(GridValue(s, row + 1, col - 1), GridValue(s, row + 1, col), GridValue(s, row + 1, col + 1), GridValue(s, row + 1, col + 2), c - col, &f2, &df2dc);
-  CubicHermite(GridValue(s, row + 2, col - 1), GridValue(s, row + 2, col), GridValue(s, row + 2, col + 1), GridValue(s, row + 2, col + 2), c - col, &f3, &df3dc);
-  CubicHermite(f0, f1, f2, f3, r - row, f, dfdr);
-  if (dfdc) CubicHermite(df0dc, df1dc, df2dc, df3dc, r - row, dfdc, nullptr);
-}
-inline double InterpEval(const Scene& s, double r, double c) { double f; BiCubic(s, r, c, &f, nullptr, nullptr); return f; }
 inline Jet InterpEval(const Scene& s, const Jet& r, const Jet& c) {
   double f, dfdr, dfdc;
   BiCubic(s, r.a, c.a, &f, &dfdr, &dfdc);
   Jet h; h.a = f;
   for (int k = 0; k < kStride; ++k) h.v[k] = dfdr * r.v[k] + dfdc * c.v[k];
   return h;
-}
-
-// a5  ObstacleCost (critics/obstacle_cost_function.hpp:137-167)
-template <typename T>
-T ObstacleResidual(const Scene& s, T const* const* parameters, int i) {
-  T x, y, th;
-  Rollout(s, parameters, i, &x, &y, &th);
-  const T front_offset = T(0.25);                                                // :152
-  T front_x = x + front_offset * Cos(th);                                        // :154
-  T front_y = y + front_offset * Sin(th);                                        // :155
-  T ix = (front_x - T(s.origin_x)) / T(s.resolution);                            // :158-159
-  T iy = (front_y - T(s.origin_y)) / T(s.resolution);
-  T value_front = InterpEval(s, iy, ix);                                         // :161 Evaluate(row = y, col = x)
-  return T(s.prm->obstacle_w) * value_front;                                     // :164
-}
-
-// a9  VelocityFeasibilityCost (critics/velocity_feasibility_cost_function.hpp:86-98)
-template <typename T>
-T VelocityFeasibilityResidual(const Scene& s, const T* state1, const T* state2, int i) {
-  if (i < s.d.CH) {
-    T lin = state1[0] - state2[0];
-    T ang = state1[1] - state2[1];
-    return T(s.prm->velocity_feasibility_w) * lin * lin + T(s.prm->velocity_feasibility_w) * ang * ang;
-  }
-  return T(0.0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// a10  Problem assembly (src/optimizer.cpp:241-379): residual order and parameter-block visibility.
-// ------------------------------------------------------------------------------------------------
-enum Kind { kAgentAngle, kSocialWork, kProxemics, kVelocity, kGoalAlign, kDistFollow, kDistAlign, kObstacle, kVelFeas };
-struct Block { Kind kind; int i; };
-
-std::vector<Block> BuildBlocks(const Dims& d) {
-  std::vector<Block> blocks;
-  for (int i = 0; i < d.T; ++i) {
-    if (d.has_people) {                                  // :263, order of AddResidualBlock :292-294
-      blocks.push_back({kAgentAngle, i});
-      blocks.push_back({kSocialWork, i});
-      blocks.push_back({kProxemics, i});
-    }
-    blocks.push_back({kVelocity, i});                    // :323
-    blocks.push_back({kGoalAlign, i});                   // :324
-    blocks.push_back({kDistFollow, i});                  // :361
-    blocks.push_back({kDistAlign, i});                   // :362
-    blocks.push_back({kObstacle, i});                    // :363
-    if (i != 0 && i < d.CH / d.bl) blocks.push_back({kVelFeas, i});  // :364-370
-  }
-  return blocks;
-}
-
-template <typename T>
-T EvalDynamic(const Scene& s, const Block& b, T const* const* parameters) {
-  switch (b.kind) {
-    case kAgentAngle: return AgentAngleResidual<T>(s, parameters, b.i);
-    case kSocialWork: return SocialWorkResidual<T>(s, parameters, b.i);
-    case kProxemics: return ProxemicsResidual<T>(s, parameters, b.i);
-    case kVelocity: return VelocityResidual<T>(s, parameters, b.i);
-    case kGoalAlign: return GoalAlignResidual<T>(s, parameters, b.i);
-    case kDistFollow: return DistanceResidual<T>(s, parameters, b.i, s.prm->distance_w, s.path_pts[2 * s.d.T], s.path_pts[2 * s.d.T + 1]);  // :234-235,330-331
-    case kDistAlign: return DistanceResidual<T>(s, parameters, b.i, s.prm->angle_w, s.path_pts[2 * (b.i + 1)], s.path_pts[2 * (b.i + 1) + 1]);  // :327,333-334
-    case kObstacle: return ObstacleResidual<T>(s, parameters, b.i);
-    default: return T(0.0);
-  }
 }
 
 // Evaluate all residual blocks at x. jac (M x P, row-major, may be null) is filled the way
@@ -1051,25 +722,6 @@ void Unpack(const Scene& s, const std::vector<double>& x, double* cmds, double* 
       path[3 * i] = px; path[3 * i + 1] = py; path[3 * i + 2] = GetYaw(qz, qw);
     }
   }
-}
-
-bool MakeScene(const smpc_params* prm, const smpc_scene_batch* sb, int b, Scene* s) {
-  const int T = sb->T, N = sb->N;
-  const bool hp = sb->has_people ? sb->has_people[b] != 0 : (N > 0);
-  s->d = MakeDims(*prm, T, N, hp);
-  s->dt = sb->dt;
-  s->x0 = sb->pose0[3 * b]; s->y0 = sb->pose0[3 * b + 1]; s->yaw0 = sb->pose0[3 * b + 2];
-  s->path_pts = sb->path_pts + static_cast<size_t>(b) * (T + 1) * 2;
-  s->goal_yaw = sb->goal_yaw[b];
-  s->people = sb->people ? sb->people + static_cast<size_t>(b) * (T + 1) * 6 * N : nullptr;
-  const size_t cm = static_cast<size_t>(sb->size_x) * sb->size_y;
-  s->costmap = sb->costmap + (sb->costmap_shared ? 0 : cm * b);
-  s->size_x = sb->size_x; s->size_y = sb->size_y;
-  s->origin_x = sb->costmap_origin[sb->costmap_shared ? 0 : 2 * b];
-  s->origin_y = sb->costmap_origin[sb->costmap_shared ? 1 : 2 * b + 1];
-  s->resolution = sb->resolution;
-  s->prm = prm;
-  return s->d.nb <= SMPC_MAX_BLOCKS;
 }
 
 void SolveOne(const smpc_params* prm, const smpc_scene_batch* sb, int b, smpc_result_batch* out, std::vector<TraceRow>* trace, int32_t* sign_events = nullptr, int32_t* marginal = nullptr) {
