@@ -24,7 +24,7 @@ double shortest_angular_distance(double from, double to)
 }
 }  // namespace
 
-void SocialMPCController::configure(const ControllerParams & params)
+void SocialMPCControllerCore::configure(const ControllerParams & params)
 {
   fov_angle_ = params.fov_angle;
   trajectorizer_ = std::make_unique<PathTrajectorizer>();
@@ -33,7 +33,7 @@ void SocialMPCController::configure(const ControllerParams & params)
   optimizer_->initialize(params.optimizer);
 }
 
-people_msgs::msg::People SocialMPCController::filterPeople(
+people_msgs::msg::People SocialMPCControllerCore::filterPeople(
   const people_msgs::msg::People & people_unf, const geometry_msgs::msg::PoseStamped & robot_pose) const
 {
   people_msgs::msg::People people;
@@ -50,7 +50,7 @@ people_msgs::msg::People SocialMPCController::filterPeople(
   return people;
 }
 
-geometry_msgs::msg::TwistStamped SocialMPCController::computeVelocityCommands(
+geometry_msgs::msg::TwistStamped SocialMPCControllerCore::computeVelocityCommands(
   const geometry_msgs::msg::PoseStamped & robot_pose, const geometry_msgs::msg::Twist & speed, void * /*goal_checker*/)
 {
   if (!trajectorizer_ || !optimizer_) throw std::runtime_error("SocialMPCController::configure was not called");
@@ -90,7 +90,7 @@ extern "C" int smpc_host_fov_filter(const double * people_xy, int n, const doubl
                                     double origin_x, double origin_y, int size_x, int size_y, double resolution, int * keep)
 {
   using namespace nav2_social_mpc_controller;
-  class Probe : public SocialMPCController { public: void fov(double a) { fov_angle_ = a; } } c;
+  class Probe : public SocialMPCControllerCore { public: void fov(double a) { fov_angle_ = a; } } c;
   c.fov(fov_angle);
   nav2_costmap_2d::Costmap2D cm(size_x, size_y, resolution, origin_x, origin_y);
   c.setCostmap(&cm);

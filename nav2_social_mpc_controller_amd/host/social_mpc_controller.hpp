@@ -3,7 +3,9 @@
 // than ROS plumbing: trajectorize -> field-of-view filter -> optimize -> fallbacks -> first command. SURVEY §8 row f4
 // proper (pluginlib export, lifecycle node, subscribers, TF, RViz markers, PathHandler's transform / prune of the global
 // plan) needs ROS 2 / Nav2, which this image does not have; here the inputs those parts deliver are handed in directly.
-// Method names follow nav2_core::Controller so that a maintainer can lay the real shell over it.
+// Method names follow nav2_core::Controller; the real shell — class SocialMPCController : public nav2_core::Controller with
+// the pluginlib export — is host/ros/social_mpc_controller_plugin.{hpp,cpp} (needs ROS 2 / Nav2: -DSMPC_HOST_WITH_ROS)
+// and is laid over this class.
 #pragma once
 #include <memory>
 #include <vector>
@@ -21,7 +23,7 @@ struct ControllerParams
   OptimizerParams optimizer;
 };
 
-class SocialMPCController
+class SocialMPCControllerCore
 {
 public:
   void configure(const ControllerParams & params);
@@ -59,5 +61,10 @@ protected:
   AgentsTrajectories last_people_;
   bool last_optimized_ = false;
 };
+
+#ifndef SMPC_HOST_WITH_ROS
+// without ROS the core answers to the reference's class name (tests, demos); with ROS that name belongs to the plugin
+using SocialMPCController = SocialMPCControllerCore;
+#endif
 
 }  // namespace nav2_social_mpc_controller

@@ -119,3 +119,40 @@ def test_controller_ticks_match_oracle(built, oracle, tmp_path):
         assert np.all(sc.people[0, :, 3, 1:] == -1.0)                   # two phantoms: only the person ahead passed the filter
         cmd = [float(v) for v in lines[tick].split("cmd=(")[1].split(")")[0].split(",")]
         assert abs(cmd[0] - d["cmds"][0]) <= 1e-9 and abs(cmd[1] - d["cmds"][1]) <= 1e-9   # the command returned = cmds[0]
+
+
+def test_ros_plugin_shell_sources_keep_the_reference_interface():
+    """host/ros/: the nav2_core::Controller plugin over the solver (SURVEY §8 row f4). ROS 2 / Nav2 are absent from this
+    image, so the sources cannot be compiled here; what can be checked is that they declare the reference's interface
+    (include/nav2_social_mpc_controller/social_mpc_controller.hpp:70-112) and export the reference's type string
+    (src/social_mpc_controller.cpp:325, nav2_social_mpc_controller.xml), and that nothing in the default build needs them."""
+    import re
+    ros = os.path.join(HOST, "ros")
+    hpp = open(os.path.join(ros, "social_mpc_controller_plugin.hpp")).read()
+    cpp = open(os.path.join(ros, "social_mpc_controller_plugin.cpp")).read()
+    xml = open(os.path.join(ros, "nav2_social_mpc_controller.xml")).read()
+    cmake = open(os.path.join(ros, "CMakeLists.txt")).read()
+    assert re.search(r"class SocialMPCController\s*:\s*public nav2_core::Controller", hpp)
+    flat = re.sub(r"\s+", " ", hpp)
+    for sig in ("void configure( const rclcpp_lifecycle::LifecycleNode::WeakPtr & parent, std::string name, "
+                "std::shared_ptr<tf2_ros::Buffer> tf, std::shared_ptr<nav2_costmap_2d::Costmap2DROS> costmap_ros) override;",
+                "void cleanup() override;", "void activate() override;", "void deactivate() override;",
+                "geometry_msgs::msg::TwistStamped computeVelocityCommands( const geometry_msgs::msg::PoseStamped & pose, "
+                "const geometry_msgs::msg::Twist & velocity, nav2_core::GoalChecker * goal_checker) override;",
+                "void setPlan(const nav_msgs::msg::Path & path) override;",
+                "void setSpeedLimit(const double & speed_limit, const bool & percentage) override;"):
+        assert sig in flat, sig
+    assert "PLUGINLIB_EXPORT_CLASS(nav2_social_mpc_controller::SocialMPCController, nav2_core::Controller)" in cpp
+    assert 'type="nav2_social_mpc_controller::SocialMPCController"' in xml and 'base_class_type="nav2_core::Controller"' in xml
+    assert 'library path="nav2_social_mpc_controller"' in xml
+    assert "find_package(nav2_core QUIET)" in cmake and "SMPC_HOST_WITH_ROS" in cmake
+    assert "#error" in hpp and "SMPC_HOST_WITH_ROS" in hpp          # refuses to build without ROS instead of faking it
+    # the reference's parameter names (src/optimizer.cpp:26-84, src/path_trajectorizer.cpp:52-59, src/social_mpc_controller.cpp:58-60)
+    for key in ("fov_angle", "transform_tolerance", "omnidirectional", "lookahead_dist", "max_angular_vel", "time_step", "max_time",
+                "linear_solver_type", "param_tol", "fn_tol", "gradient_tol", "max_iterations", "debug_optimizer", "control_horizon",
+                "parameter_block_length", "current_path_weight", "current_cmds_weight", "weights.distance_weight",
+                "weights.social_weight", "weights.velocity_weight", "weights.angle_weight", "weights.agent_angle_weight",
+                "weights.proxemics_weight", "weights.velocity_feasibility_weight", "weights.obstacle_weight",
+                "weights.goal_align_weight"):
+        assert ('"' + key + '"' in cpp) or ('.' + key + '"' in cpp), key
+    assert not os.path.exists(os.path.join(ros, "ros_stubs")) and "host/ros" not in open(os.path.join(HOST, "Makefile")).read()
