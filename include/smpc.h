@@ -34,7 +34,11 @@ extern "C" {
 #define SMPC_MAX_STEPS 63  /* T <= 63: one lane per pose of the rollout (T + 1 poses in a 64-lane wavefront) */
 #define SMPC_MAX_AGENTS 64 /* N <= 64: one bit per agent in the per-step validity mask */
 
-/* linear_solver_type: mirrors OptimizerParams::solver_types (optimizer.hpp:71-77). */
+/* linear_solver_type: mirrors OptimizerParams::solver_types (optimizer.hpp:71-77). The value is validated like the
+ * reference does (src/optimizer.cpp:31-45) and otherwise has NO effect on the device: every type takes the same step
+ * solver — damped normal equations (J^T J + D^T D) delta = -J^T r by Cholesky (csrc/smpc_lm.hpp). For these problems
+ * (P <= 20 unknowns, Jacobi-scaled) that is the LM step DENSE_QR / DENSE_SCHUR compute up to round-off; the CPU oracle
+ * implements Householder QR and Schur elimination separately and tests compare against both. */
 enum smpc_linear_solver {
   SMPC_DENSE_SCHUR = 0,
   SMPC_SPARSE_SCHUR = 1,
@@ -46,6 +50,7 @@ enum smpc_linear_solver {
 /* Per-scene termination, mirrors ceres::TerminationType as far as Optimizer::optimize observes it
  * (summary.IsSolutionUsable(), src/optimizer.cpp:384). */
 enum smpc_status {
+  SMPC_NOT_SOLVED = -1,    /* only with a device-side `order` that is not a permutation: the scene was never handed out */
   SMPC_CONVERGENCE = 0,    /* usable */
   SMPC_NO_CONVERGENCE = 1, /* usable (iteration cap) */
   SMPC_FAILURE = 2         /* NOT usable: non-finite initial evaluation or 5 consecutive invalid steps */
@@ -136,8 +141,9 @@ typedef struct smpc_scene_batch {
   const double* people_aux;     /* [B][T][2]    bits of the valid-agent mask (t != -1), agent-angle target or SMPC_NO_TARGET */
 
   /* Optional scheduling hint of smpc_solve_batch: the order in which the persistent kernel's queue hands out the
-   * scenes, a permutation of 0..B-1 (checked for host arrays, trusted for device arrays: a value outside 0..B-1 is
-   * skipped, a repeated one is solved twice). Results do not depend on it (every scene is solved by its own lanes
+   * scenes, a permutation of 0..B-1 (checked for host arrays; for device arrays a value outside 0..B-1 is skipped and a
+   * repeated one is solved twice — the scene such an order leaves out is not solved: its status reads SMPC_NOT_SOLVED
+   * and its other result rows are unspecified). Results do not depend on it (every scene is solved by its own lanes
    * from its own inputs); the duration of a launch that has the GPU to itself does: scenes that need many sweeps
    * should come first, e.g. sorted by the `evaluations` of the previous control period (a launch in index order ends
    * with a tail of late-started long scenes: 3.25 ms against 2.40 ms longest-first at the headline batch). NULL:

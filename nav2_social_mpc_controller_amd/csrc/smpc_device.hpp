@@ -57,6 +57,8 @@ struct KParams {
   const double* people_rec;  // [B][N][T][4]  px, py, vx, vy of people_proj[t + 1][a]
   const double* people_aux;  // [B][T][2]     bit mask of valid agents (u64 bits), agent-angle target (kNoTarget: none)
   const int32_t* order;      // [B] queue order of the solve kernel (null: index order)
+  int hp_A;                  // helper lanes (W = 64 kernels, see sweep()): agents the owner lane of a step walks itself;
+                             // == N: no helpers. Agents hp_A .. N-1 of every step are walked by the lanes beyond the horizon
   int prio_step;             // > 0: a wave whose oldest scene has made n sweeps runs at wave priority min(n / prio_step, 3)
   double* stage_rec;         // staging kernel outputs (same layouts)
   double* stage_aux;
@@ -98,11 +100,13 @@ struct LdsLayout {
   int cs;       // [2][T+1]   cos, sin of theta_j, j = 0..T
   int inc;      // [4][T+1]   inclusive scans over j of cos, sin, j cos, j sin(theta_j) of the current sweep
   int cst;      // [8]        x0, y0, yaw0, goal_yaw, origin x, origin y, final point x, y
+  int stepst;   // [4][T]     helper lanes only: robot x, y, velocity x, y at every step (what a pair evaluation needs of it)
+  int part;     // [T][kPart] helper lanes only: the partial sums a helper hands to the owner lane of a step
   int hz;       // [4]        the scene's own horizon (kernels with per-scene T): ints T, CH, bl, last block, feasibility
                 //            rows, bounded blocks
   int lanec;    // [3][T]     per step: path point x, y (path_pts[t+1]) and agent-angle target (kNoTarget = none)
   int lm;       // LM vectors / matrices / scalars
-  int gram;     // [(P+1)^2] Gram of the latest sweep (VALU back-end; the MFMA back-end uses the wave's result tile)
+  int gram;     // [(P+1)^2] Gram [J r]^T [J r] of the latest sweep, dense and symmetric
   int scratch;  // polynomial scratch
   int total;
 };
@@ -111,6 +115,26 @@ enum LayoutKind { kLayoutEval = 0, kLayoutSolve = 1, kLayoutStage = 2 };
 
 // kLayoutSolve: LM state in LDS. kLayoutEval: the stand-alone K1 kernel, a single sweep. kLayoutStage: the staging
 // kernel, people block in LDS on its way to the staged records.
+constexpr int kPart = 18;  // 6 + 4 + 1 + 4 partial sums, nearest distance, its agent index, redo flag (+ 1 spare)
+
+// Helper lanes. With one scene per wave (W = 64) the lanes beyond the horizon (64 - T of them) idle through the agent loop,
+// the longest part of a sweep. They take over the tail of every step's agent list instead: the owner lane of step t walks
+// agents 0 .. A-1, one helper walks agents A .. N-1 of step t (a "unit"), helper h taking the units h, h + R, h + 2R, ...
+// (R = 64 - T helpers, U = ceil(T / R) units each) and handing the partial sums of each unit to its owner through LDS.
+// A is the smallest count with U (N - A) <= A: owners and helpers then finish together after A iterations instead of N
+// (BASELINE configs[4]: N = 16, T = 38 -> A = 11; params.yaml shape N = 3 -> A = 2). Returns N when helpers do not
+// pay (each unit costs a flush of ~30 instructions, the hand-over another ~40 per step).
+__host__ __device__ inline int helper_owner_agents(int T, int N, int W) {
+  const int R = W - T;
+  if (W != 64 || R < 1 || N < 2) return N;
+  const int U = (T + R - 1) / R;
+  const int A = (U * N + U) / (U + 1);            // ceil(U N / (U + 1))
+  if (A >= N) return N;
+  // instructions saved per sweep against the hand-over's, with a margin of two: measured, the params.yaml shape (N = 3:
+  // one pair saved, two units flushed) gained nothing, BASELINE configs[4] (five pairs saved) 14 %
+  return ((N - A) * 250 > 2 * (60 * U + 120)) ? A : N;
+}
+
 __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) {
   LdsLayout L;
   const bool with_lm = kind == kLayoutSolve;
@@ -126,6 +150,8 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
   }
   L.cst = o; o += 8;
   L.hz = o; o += 4;
+  L.stepst = o; L.part = o;
+  if (kind != kLayoutStage && helper_owner_agents(T, N, (T + 1 <= 32 && N <= 32) ? 32 : 64) < N) { o += 4 * T; L.part = o; o += kPart * T; }
   L.lanec = o; o += 3 * T;
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;  // Hs, six vectors, scalars: what lives from trip to trip
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)
@@ -485,7 +511,7 @@ struct Ctx {
   const uint8_t* map;
   double* lds;       // this slot's LDS block (scene constants, cos/sin block, LM state live here)
   const double* ag;  // staged people records [N][T][4] of this slot's scene (global memory)
-  double* wave_lds;  // wave-shared LDS behind the slot blocks (MFMA row tile + result tile)
+  double* wave_lds;  // wave-shared LDS behind the slot blocks (solve: feasibility rows of every slot; K1: row staging blocks)
   LdsLayout L;
 };
 
@@ -667,7 +693,7 @@ __device__ inline void load_scene(Ctx& c, int scene) {
 // reduced over the slot in every lane of the slot.
 // When out_r / out_J are non-null (stand-alone K1) the rows are also written to HBM in the reference order.
 // ------------------------------------------------------------------------------------------------
-// kRows = false: the solve kernel's sweep, full Gram [J r]^T [J r] (MFMA back-end where it fits), nothing written.
+// kRows = false: the solve kernel's sweep, full Gram [J r]^T [J r] (structured, on the VALU), nothing written.
 // kRows = true: the stand-alone K1 sweep; rows go to HBM, and of the Gram only its last column (J^T r and r^T r: the
 // gradient and the cost smpc_eval_batch reports) is accumulated, on the VALU — c.wave_lds is then the row staging
 // area of the critic-major store path (2 x T x P doubles per slot).
@@ -775,22 +801,19 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
     int pidx = 0;  // proxemics: index of the nearest valid agent (first minimum wins: std::min on duals)
     bool redo = false;  // some pair of this lane is not a regular one
-    for (int a = 0; a < N; ++a) {
-      // records are fetched two agents ahead (the first two before the rollout, above): HBM latency in K1, L2 in a solve
-      const double apx = rec0[0], apy = rec0[1], awx = rec0[2], awy = rec0[3];
-      rec0 = rec1;
-      if (a + 2 < N) rec1 = agr[(a + 2) * T];
-      const bool valid = (vm >> a) & 1ull;
-      const double dx = X - apx, dy = Y - apy;
+    // One robot-agent pair: the robot of a step at (px, py) with velocity (pvx, pvy) against agent a of that step.
+    // One evaluation serves both directions: the force on the robot from the agent (:125; valid agents only, :175)
+    // is F(diff, u), diff = robot - agent, u = robotVel - agentVel; the force on the agent from the robot
+    // (:137-143; every column, phantoms included) is F(-diff, -u) = -F with the same derivatives, so |.|^2 and its
+    // gradient are those of F.
+    auto pair = [&](const v4d& rec, int a, bool valid, double px, double py, double pvx, double pvy) {
+      const double apx = rec[0], apy = rec[1], awx = rec[2], awy = rec[3];
+      const double dx = px - apx, dy = py - apy;
       const double d2 = fma(dx, dx, dy * dy);
       const bool nearer = valid & (d2 < pbest);
       pbest = nearer ? d2 : pbest;
       pidx = nearer ? a : pidx;
-      // One evaluation serves both directions: the force on the robot from the agent (:125; valid agents only, :175)
-      // is F(diff, u), diff = robot - agent, u = robotVel - agentVel; the force on the agent from the robot
-      // (:137-143; every column, phantoms included) is F(-diff, -u) = -F with the same derivatives, so |.|^2 and its
-      // gradient are those of F.
-      const Force F = pair_force(mt, dx, dy, rvx - awx, rvy - awy);
+      const Force F = pair_force(mt, dx, dy, pvx - awx, pvy - awy);
       redo |= F.special | (d2 < 1e-12);  // |diff| < 1e-6 -> diff := (1e-6, 0), :181-184, breaks the symmetry above
       const double m = valid ? 1.0 : 0.0;
       soc[0] = fma(m, F.fx, soc[0]); soc[1] = fma(m, F.fy, soc[1]);
@@ -806,6 +829,82 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       qh[1] = fma(F.fx, F.dfx_dy, fma(F.fy, F.dfy_dy, qh[1]));
       qh[2] = fma(F.fx, F.dfx_dux, fma(F.fy, F.dfy_dux, qh[2]));
       qh[3] = fma(F.fx, F.dfx_duy, fma(F.fy, F.dfy_duy, qh[3]));
+    };
+    const int A = (W == 64) ? k.hp_A : N;  // agents the owner lane walks itself (helper_owner_agents(): N without helpers)
+    if (W == 64 && A < N) {
+      // ---- with helper lanes (see helper_owner_agents()): lanes sl >= T walk agents A .. N-1 of the steps h, h + R, ...
+      const int NA = N - A, R = W - T;
+      double* stp = c.lds + c.L.stepst;
+      double* part = c.lds + c.L.part;
+      const bool helper = sl >= T;
+      if (sl < Th) { stp[sl] = X; stp[T + sl] = Y; stp[2 * T + sl] = rvx; stp[3 * T + sl] = rvy; }
+      wave_lds_fence();
+      // the step this lane currently works for, and what a pair evaluation needs of it
+      int t_cur = helper ? sl - T : tl;
+      bool unit_ok = helper ? (t_cur < Th) : (sl < Th);
+      double cX = X, cY = Y, cvx = rvx, cvy = rvy;
+      unsigned long long cvm = vm;
+      if (helper) {
+        const int ts = min(t_cur, Th - 1);
+        cX = stp[ts]; cY = stp[T + ts]; cvx = stp[2 * T + ts]; cvy = stp[3 * T + ts]; cvm = vmask[ts];
+      }
+      int a_cur = helper ? A : 0, k_in = 0;
+      const v4d* recs = reinterpret_cast<const v4d*>(c.ag);  // record of agent a at step t: recs[a * T + t]
+      v4d rec_next = recs[a_cur * T + min(t_cur, Th - 1)];
+      for (int it = 0; it < A; ++it) {
+        const v4d rec = rec_next;
+        // where this lane goes next (a helper that has finished a unit moves R steps on), fetched one pair ahead
+        const bool unit_end = helper && (k_in + 1 == NA);
+        const int t_next = unit_end ? t_cur + R : t_cur;
+        const int a_next = unit_end ? A : a_cur + 1;
+        rec_next = recs[min(a_next, N - 1) * T + min(t_next, Th - 1)];
+        if (unit_ok) pair(rec, a_cur, (cvm >> a_cur) & 1ull, cX, cY, cvx, cvy);
+        if (unit_end) {
+          if (unit_ok) {  // hand the unit's sums to the owner lane of its step
+            double* pr = part + t_cur * kPart;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pr[i] = soc[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { pr[6 + i] = su[i]; pr[11 + i] = qh[i]; }
+            pr[10] = soc[10];
+            pr[15] = pbest;
+            pr[16] = (double)(pidx + (redo ? 4096 : 0));
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) soc[i] = 0.0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { su[i] = 0.0; qh[i] = 0.0; }
+          soc[10] = 0.0; pbest = 1.7976931348623157e308; pidx = 0; redo = false;
+          unit_ok = t_next < Th;
+          const int ts = min(t_next, Th - 1);
+          cX = stp[ts]; cY = stp[T + ts]; cvx = stp[2 * T + ts]; cvy = stp[3 * T + ts]; cvm = vmask[ts];
+          k_in = 0;
+        } else {
+          k_in += helper ? 1 : 0;
+        }
+        t_cur = t_next; a_cur = a_next;
+      }
+      wave_lds_fence();
+      if (!helper && sl < Th) {  // the owner adds what the helper found for its step
+        const double* pr = part + sl * kPart;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) soc[i] += pr[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { su[i] += pr[6 + i]; qh[i] += pr[11 + i]; }
+        soc[10] += pr[10];
+        const int tag = (int)pr[16];
+        // the helper's agents come after the owner's: a tie stays with the owner (std::min keeps the first minimum)
+        if (pr[15] < pbest) { pbest = pr[15]; pidx = tag & 4095; }
+        redo |= tag >= 4096;
+      }
+    } else {
+      for (int a = 0; a < N; ++a) {
+        // records are fetched two agents ahead (the first two before the rollout, above): HBM latency in K1, L2 in a solve
+        const v4d rec = rec0;
+        rec0 = rec1;
+        if (a + 2 < N) rec1 = agr[(a + 2) * T];
+        pair(rec, a, (vm >> a) & 1ull, X, Y, rvx, rvy);
+      }
     }
     {  // the constant factors pair_force() leaves out, once per step instead of once per pair
       const double kk = kPairForceK, kl = kPairForceK * kPairForceLambda, k2 = kPairForceK * kPairForceK,

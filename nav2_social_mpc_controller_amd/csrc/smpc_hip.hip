@@ -176,6 +176,8 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
   k->dt = sb->dt; k->resolution = sb->resolution; k->inv_resolution = 1.0 / sb->resolution;
   k->prm = h->prm;
   k->e_M = d.M;
+  k->hp_A = smpc::helper_owner_agents(sb->T, sb->N, smpc::slot_width(sb->T, sb->N));
+  if (std::getenv("SMPC_NO_HELPERS")) k->hp_A = sb->N;  // experiment knob (the LDS layout keeps the helper regions)
   smpc::fill_math_table(&k->mt);
 }
 
@@ -281,7 +283,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   const int S = smpc::kWave / W;
   KernelFn fn = pick(k.nb, W, eval, k.T_scene != nullptr);
   const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve);
-  // behind the slot blocks: the MFMA row / result tiles (solve) or the two row staging blocks per slot (K1)
+  // behind the slot blocks: the feasibility rows of every slot (solve) or the row staging blocks + parked sensitivities (K1)
   const size_t extra = eval ? (size_t)smpc::eval_extra_doubles(k.T, k.P, W) : (size_t)smpc::wave_extra_doubles(k.P, W);
   const size_t shmem = ((size_t)S * L.total + extra) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
@@ -333,7 +335,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     double tot[12] = {0};
     for (int g = 0; g < grid; ++g) for (int i = 0; i < 12; ++i) tot[i] += (double)hs[(size_t)g * 12 + i];
     double all = 0; for (int i = 0; i < 8; ++i) all += tot[i];
-    static const char* names[8] = {"fetch+load_scene", "theta+sincos", "xy-loop", "agent-loop", "sens-loop", "rows+mfma+gram", "lm+output", "ls-interpolation"};
+    static const char* names[8] = {"fetch+load_scene", "theta+sincos", "xy-loop", "agent-loop", "sens-loop", "critics+gram", "lm+output", "ls-interpolation"};
     std::fprintf(stderr, "[stamps %s] grid=%d mean cycles/wave=%.0f:", eval ? "K1" : "solve", grid, all / grid);
     for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * tot[i] / all);
     std::fprintf(stderr, " | rows split: people-critics=%.1f%% vel/goal/dist=%.1f%% obstacle=%.1f%% (rest of rows = feas + gram out)\n",
@@ -508,6 +510,9 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   if (sb->on_device) {
     k.o_params = out->params; k.o_cmds = out->cmds; k.o_path = out->path; k.o_status = out->status; k.o_reason = out->reason;
     k.o_iterations = out->iterations; k.o_evaluations = out->evaluations; k.o_initial_cost = out->initial_cost; k.o_final_cost = out->final_cost;
+    // a device-side order cannot be checked here: should it not be a permutation, the scenes it leaves out must not keep
+    // the status of an earlier call — every status starts as SMPC_NOT_SOLVED (-1) and is overwritten by the scene's solve
+    if (k.order && k.o_status && sb->B > 0) SMPC_HIP_CHECK(hipMemsetAsync(k.o_status, 0xFF, (size_t)sb->B * sizeof(int32_t), h->stream));
     return launch(h, false, k);
   }
   SMPC_TRY(st.out(out->params, B * d.P, &k.o_params));

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(64) void smpc_plan_window_kernel(const WindowParams
   int imin = 0x7fffffff;
   for (int i = start + lane; i < upper; i += 64) {
     const double d = hypot(rx - plan[2 * i], ry - plan[2 * i + 1]);
-    if (imin == 0x7fffffff || d < dmin) { dmin = d; imin = i; }
+    // (a NaN distance a lane met first must not shadow the finite ones it meets later: min_by only lets a NaN stick
+    // when it is the first element of the WHOLE range, which the rule behind the reduction below restores)
+    if (imin == 0x7fffffff || d < dmin || (dmin != dmin && d == d)) { dmin = d; imin = i; }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {

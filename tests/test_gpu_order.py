@@ -37,8 +37,9 @@ def test_a_host_order_that_is_not_a_permutation_is_refused():
 
 @pytest.mark.gpu
 def test_device_order_entries_outside_the_batch_are_skipped():
-    """Device arrays are trusted, but a wrong entry must not become an out-of-bounds scene index: it is skipped (that
-    scene keeps whatever its output arrays held)."""
+    """Device arrays cannot be checked on the host, but a wrong entry must not become an out-of-bounds scene index: it
+    is skipped, and the scene such an order leaves out must not look solved: its status reads SMPC_NOT_SOLVED (-1), not
+    whatever an earlier call left there. A repeated entry solves that scene twice (same result) and leaves another out."""
     import torch
 
     from nav2_social_mpc_controller_amd.solver import BatchSolver
@@ -54,13 +55,14 @@ def test_device_order_entries_outside_the_batch_are_skipped():
     order = torch.arange(B, dtype=torch.int32, device="cuda:0").flip(0).contiguous()
     order[3] = B + 1000     # scene B-4 is never handed out
     order[10] = -5          # scene B-11 neither
+    order[20] = order[21]   # scene B-21 is replaced by a second B-22
     sb.order = order.data_ptr()
     s.solve_device(sb, rb)
     torch.cuda.synchronize()
     st = rt["status"].cpu().numpy()
     skipped = np.zeros(B, bool)
-    skipped[[B - 4, B - 11]] = True
-    assert (st[skipped] == -7).all()
+    skipped[[B - 4, B - 11, B - 21]] = True
+    assert (st[skipped] == -1).all()
     assert np.array_equal(st[~skipped], base["status"][~skipped])
     assert np.array_equal(rt["cmds"].cpu().numpy()[~skipped], base["cmds"][~skipped])
 

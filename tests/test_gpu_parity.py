@@ -42,7 +42,7 @@ EVAL_CASES = {
     "quirk_bl_not_dividing_ch": (README.replace(time_step=0.1), dict(B=32, N=3, seed=107)),
     "all_agents_invalid": (README, dict(B=16, N=3, n_valid=0, seed=108)),
     "single_block": (README.replace(control_horizon=4, parameter_block_length=6), dict(B=16, N=5, seed=109)),
-    # T=28 (two scenes per wave) with 5 parameter blocks: [J r] has 11 columns -> VALU Gram back-end instead of MFMA
+    # T=28 (two scenes per wave) with 5 parameter blocks: [J r] has 11 columns (66 Gram entries, five reduction chunks)
     "w32_five_blocks_valu_gram": (README.replace(parameter_block_length=4), dict(B=32, N=6, seed=110)),
     "six_blocks": (README.replace(parameter_block_length=3), dict(B=16, N=4, seed=111)),
     # up to SMPC_MAX_BLOCKS = 10 parameter blocks (P = 20): control_horizon 30 over T = 38
@@ -142,12 +142,12 @@ def test_solve_matches_oracle_on_seeded_scenes(Solver, oracle, name):
     #     a margin above rounding noise (1e-12 of the cost) must agree; the few others are counted and must still end
     #     on an equally good optimum
     rz = oracle.solve(prm, sc, nthreads=16, theta_zero_convention=True)
-    stable = well_conditioned(oracle, prm, sc, rz, nthreads=16, theta_zero_convention=True)
-    assert stable.mean() >= 0.97, f"only {stable.sum()}/{len(stable)} scenes are well conditioned"
+    stable = well_conditioned(oracle, prm, sc, rz, nthreads=16, theta_zero_convention=True, samples=2)
+    assert stable.mean() >= 0.97, f"only {stable.sum()}/{len(stable)} scenes are well conditioned: {np.where(~stable)[0]}"
     firm = (rz["marginal_decisions"] == 0) & stable
     assert firm.mean() >= 0.9, f"only {firm.sum()}/{len(firm)} scenes have firm decisions"
     err = cmd_err(rg["cmds"], rz["cmds"])
-    assert np.max(err[firm]) <= CMD_TOL
+    assert np.max(err[firm]) <= CMD_TOL, (float(np.max(err[firm])), np.where(firm & (err > CMD_TOL))[0])
     assert np.array_equal(rg["status"][firm], rz["status"][firm])
     assert np.array_equal(rg["iterations"][firm], rz["iterations"][firm])
     assert np.max(np.abs(rg["path"][firm][:, :, :2] - rz["path"][firm][:, :, :2])) <= 1e-5
@@ -157,11 +157,16 @@ def test_solve_matches_oracle_on_seeded_scenes(Solver, oracle, name):
     # path; every one of them must still be usable, and those that did move must be few and end on a cost that is not
     # worse than the oracle's beyond the solver's own function tolerance band
     moved = ~firm & (err > CMD_TOL)
-    assert moved.mean() <= 0.03, f"{moved.sum()} scenes moved"
-    assert np.all(rg["status"][~firm] != 2)
-    if moved.any():
-        worse = (rg["final_cost"][moved] - rz["final_cost"][moved]) / rz["final_cost"][moved]
-        assert np.all(worse <= 10 * prm.fn_tol), worse
+    assert moved.mean() <= 0.03, f"{moved.sum()} scenes moved: {np.where(moved)[0]}"
+    # the set-aside scenes are not waved through: every one is usable, within the iteration cap, started from the same
+    # cost, and ends on a cost that is not worse than the oracle's beyond the solver's own function-tolerance band
+    # (a table-math or line-search defect would show here first: these are the scenes that run longest)
+    out = ~firm
+    assert np.all(rg["status"][out] != 2), np.where(out & (rg["status"] == 2))[0]
+    assert np.all(rg["iterations"][out] <= prm.max_iterations)
+    assert np.allclose(rg["initial_cost"][out], rz["initial_cost"][out], rtol=1e-10)
+    worse = (rg["final_cost"][out] - rz["final_cost"][out]) / np.maximum(rz["final_cost"][out], 1e-300)
+    assert np.all(worse <= 10 * prm.fn_tol), (np.where(out)[0][worse > 10 * prm.fn_tol], worse.max())
     # (2) the reference-literal oracle on every scene it flagged neither for libm sign noise nor for marginal decisions
     ro = oracle.solve(prm, sc, nthreads=16)
     clean = (ro["sign_noise_events"] == 0) & (ro["marginal_decisions"] == 0) & stable

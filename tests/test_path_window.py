@@ -86,6 +86,31 @@ def test_gpu_plan_window_matches_the_checker(L):
 
 
 @pytest.mark.gpu
+def test_gpu_plan_window_with_nan_poses():
+    """nav2_util::min_by moves on a strict < only: a NaN distance in the middle of the searched range is skipped, a NaN at
+    its first element stays the "lowest". Plans with one NaN pose, placed so that some lane of the lane-strided search
+    meets the NaN before finite distances (positions start + lane and start + lane + 64), and at the first element."""
+    from nav2_social_mpc_controller_amd.params import OptimizerParams
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+    s = BatchSolver(OptimizerParams.readme())
+    B, L = 12, 300
+    plan, plan_len, pose = make_plans(77, B, L)
+    start = np.zeros(B, np.int32)
+    where = [3, 17, 63, 64, 65, 100, 129, 0, 5, 70, 2, 40]    # scene 7: the first element of the range
+    for b, i in enumerate(where):
+        plan[b, i] = np.nan
+        pose[b, :2] = plan[b, min(i + 64, L - 1)] + 0.01      # the closest pose is one the NaN's lane visits later
+    search, thr = 30.0, 2.0                                    # the whole plan is searched
+    before = start.copy()
+    got = s.transform_global_plan(plan, plan_len, start, pose, search, thr)
+    from oracle import pyref_path_handler
+    for b in range(B):
+        win, ns, err = pyref_path_handler.transform_global_plan(plan[b, :plan_len[b]], int(before[b]), pose[b], search, thr)
+        assert start[b] == ns and got["window_len"][b] == len(win) and got["error"][b] == err, (b, where[b], start[b], ns)
+    assert start[7] == 0 and (start[[0, 1, 2, 3]] > 0).all()
+
+
+@pytest.mark.gpu
 def test_gpu_plan_window_exact_distances():
     """Distances that are exact in binary (3-4-5 triangles on a 1/8 m grid): the bound and threshold comparisons sit
     exactly on representable values, where a different summation order or a different hypot would show."""
