@@ -1,6 +1,7 @@
 """Development soak: tests/test_gpu_parity.py::test_randomised_parameter_sets over many more seeds than the suite runs
 (random weights / horizons / block lengths / solver types / iteration caps / crowd sizes), one line per failing case.
-usage: python tools/gpu_soak.py [first_case=100] [cases=150] [--wide]"""
+usage: python tools/gpu_soak.py [first_case=100] [cases=150] [--wide] [--horizons]
+--horizons: every scene of a case gets a horizon of its own (smpc_scene_batch.T_scene, random in 1..T)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -11,7 +12,8 @@ from nav2_social_mpc_controller_amd.scenes import make_scenes
 from nav2_social_mpc_controller_amd.solver import BatchSolver
 from oracle import oracle_py as O
 WIDE = "--wide" in sys.argv  # shapes beyond the suite's generator: up to 10 parameter blocks, T up to 59, up to 40 agents
-sys.argv = [a for a in sys.argv if a != "--wide"]
+HORIZONS = "--horizons" in sys.argv
+sys.argv = [a for a in sys.argv if a not in ("--wide", "--horizons")]
 
 
 def wide_params(rng):
@@ -36,6 +38,8 @@ for case in range(first, first + cases):
     prm = wide_params(rng) if WIDE else _random_params(rng)
     N = int(rng.integers(1, 41 if WIDE else 12))
     sc = make_scenes(prm, 48, N, seed=8000 + case, map_cells=int(rng.choice([60, 120, 200])), n_valid=int(rng.integers(1, N + 1)))
+    if HORIZONS:
+        sc = sc.with_horizons(rng.integers(1, sc.T + 1, size=sc.B).astype(np.int32))
     s = BatchSolver(prm)
     ev_o, ev_g = O.evaluate(prm, sc, sc.init_params), s.evaluate(sc, sc.init_params)
     jerr = np.max(np.abs(ev_o["jacobian"] - ev_g["jacobian"]) / np.maximum(1.0, np.abs(ev_o["jacobian"])))
