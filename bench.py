@@ -218,7 +218,7 @@ def closed_loop_extras(prm, scenes, device_index, ticks=10):
             "projection_errors": int((ep.proj_error != 0).sum().item())}
 
 
-def shape_record(prm, B, N, device, local_rank, reps=3, **scene_kw):
+def shape_record(prm, B, N, device, local_rank, reps=3, parity_scenes=128, **scene_kw):
     """One BASELINE configuration measured like the headline one, single stream: the K1 sweep (staged people block,
     critic-major rows) and the solve launch (reference-layout input), HIP events on the launching stream."""
     import numpy as np
@@ -250,13 +250,24 @@ def shape_record(prm, B, N, device, local_rank, reps=3, **scene_kw):
     st = rt["status"].cpu().numpy()
     bytes_sweep = algorithmic_bytes_per_sweep(N, T, P, M)
     del keep
+    # the oracle (checker) on the first scenes of this shape too: a sub-record that only said "failures: 0" proved nothing
+    par = None
+    if parity_scenes > 0:
+        from oracle import oracle_py as O
+        n = min(B, parity_scenes)
+        rz = O.solve(prm, sc.select(np.arange(n)), nthreads=usable_cores(), theta_zero_convention=True)
+        firm = rz["marginal_decisions"] == 0
+        d = np.abs(rt["cmds"].cpu().numpy()[:n] - rz["cmds"]).reshape(n, -1).max(axis=1)
+        par = {"scenes": int(n), "scenes_with_firm_decisions": int(firm.sum()),
+               "max_abs_dcmd": float(d[firm].max()) if firm.any() else None, "scenes_over_1e-5": int((d[firm] > 1e-5).sum()),
+               "iterations_equal_on_firm": int((rt["iterations"].cpu().numpy()[:n][firm] == rz["iterations"][firm]).sum())}
     return {"scenes": B, "people": N, "T": T, "P": P, "M": M, "slot_width": 32 if (T + 1 <= 32 and N <= 32) else 64,
             "k1_us": k1_ms * 1e3, "k1_frac_hbm": B * bytes_sweep / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stage_people_us": stage_ms * 1e3,
             "solve_ms": solve_ms, "solves_per_s": B / (solve_ms * 1e-3), "mean_sweeps_per_solve": float(ev.mean()),
             "ns_per_scene_sweep": solve_ms * 1e6 / float(ev.sum()),
             "solve_frac_hbm_algorithmic": float(ev.sum()) * bytes_sweep / (solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "bytes_per_sweep": bytes_sweep, "failures": int((st == 2).sum())}
+            "bytes_per_sweep": bytes_sweep, "failures": int((st == 2).sum()), "parity_sample": par}
 
 
 def parity_sample(prm, scenes, out, n_sample, cores):
