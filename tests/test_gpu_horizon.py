@@ -37,6 +37,10 @@ CASES = {
     "five_blocks": (README.replace(parameter_block_length=4), dict(B=64, N=4, seed=404)),
     "bl_not_dividing": (README.replace(time_step=0.1), dict(B=48, N=3, seed=405)),
     "no_people": (README, dict(B=48, N=3, seed=406, people_present=False)),
+    # one scene per wave with helper lanes (N = 16, T = 38: the lanes beyond the batch's horizon walk agents 11..15 of every
+    # step the scene HAS: units of steps beyond a scene's own horizon are skipped)
+    "cfg5_n16_helper_lanes": (README.replace(control_horizon=30, max_time=2.0), dict(B=64, N=16, seed=407)),
+    "n24_t38_helper_lanes": (README.replace(control_horizon=30, parameter_block_length=10, max_time=2.0), dict(B=48, N=24, seed=408, map_cells=120)),
 }
 
 
