@@ -261,7 +261,7 @@ def shape_record(prm, B, N, device, local_rank, reps=3, parity_scenes=128, **sce
         par = {"scenes": int(n), "scenes_with_firm_decisions": int(firm.sum()),
                "max_abs_dcmd": float(d[firm].max()) if firm.any() else None, "scenes_over_1e-5": int((d[firm] > 1e-5).sum()),
                "iterations_equal_on_firm": int((rt["iterations"].cpu().numpy()[:n][firm] == rz["iterations"][firm]).sum())}
-    return {"scenes": B, "people": N, "T": T, "P": P, "M": M, "slot_width": 32 if (T + 1 <= 32 and N <= 32) else 64,
+    return {"scenes": B, "people": N, "T": T, "P": P, "M": M, "slot_width": s.solve_slot_width(B, T, N),
             "k1_us": k1_ms * 1e3, "k1_frac_hbm": B * bytes_sweep / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "stage_people_us": stage_ms * 1e3,
             "solve_ms": solve_ms, "solves_per_s": B / (solve_ms * 1e-3), "mean_sweeps_per_solve": float(ev.mean()),

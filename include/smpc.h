@@ -243,6 +243,15 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* scenes, smpc_result
  * n < 1. */
 int smpc_set_solve_share(smpc_handle* h, int32_t n);
 
+/* Lanes of a wavefront one scene takes in a solve launch of B scenes with T rollout steps and N agents on this handle:
+ * 32 = two scenes per wave, 64 = one scene per wave (a shape with more than 31 steps or 32 agents always; a shape that
+ * would fit two per wave while the batch is small enough for every scene to have a wave of its own anyway — the lanes
+ * beyond the horizon then work as helper lanes in the agent loop, which shortens every sweep: the plugin's own B = 1
+ * call, BASELINE configs[1]). A function of (B, T, N, the handle's solve share) alone, so a scene's result never depends
+ * on timing; with four or more agents the two widths differ in the last bits of the sums over the agents. Returns a
+ * negative smpc_error for a shape smpc_solve_batch would refuse. */
+int smpc_solve_slot_width(const smpc_handle* h, int32_t B, int32_t T, int32_t N);
+
 /* Evaluate residuals / Jacobian at `params` ([B][P], same memory space) — kernel K1 alone. */
 int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* scenes, const double* params,
                     smpc_eval_batch_out* out);

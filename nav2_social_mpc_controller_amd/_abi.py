@@ -231,6 +231,7 @@ EXPORTED_SYMBOLS = [
     "smpc_destroy",
     "smpc_set_stream",
     "smpc_set_solve_share",
+    "smpc_solve_slot_width",
     "smpc_solve_batch",
     "smpc_eval_batch",
     "smpc_project_people_batch",

@@ -135,7 +135,8 @@ __host__ __device__ inline int helper_owner_agents(int T, int N, int W) {
   return ((N - A) * 250 > 2 * (60 * U + 120)) ? A : N;
 }
 
-__host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) {
+// W: the slot width of the kernel the layout is for (32: two scenes per wave, 64: one; slot_width() / solve_slot_width())
+__host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind, int W) {
   LdsLayout L;
   const bool with_lm = kind == kLayoutSolve;
   int o = 0;
@@ -144,14 +145,13 @@ __host__ __device__ inline LdsLayout make_layout(int T, int N, int P, int kind) 
   L.cs = o; o += 2 * (T + 1);
   L.inc = o; o += 4 * (T + 1);
   if (with_lm) {  // tail of the Gram reduction buffer / LM temporaries, which start at L.cs
-    const int W = (T + 1 <= 32 && N <= 32) ? 32 : 64;
     const int want = gram_red_doubles(W) > P * P + 7 * P + 96 ? gram_red_doubles(W) : P * P + 7 * P + 96;
     if (want > 6 * (T + 1)) o += want - 6 * (T + 1);
   }
   L.cst = o; o += 8;
   L.hz = o; o += 4;
   L.stepst = o; L.part = o;
-  if (kind != kLayoutStage && helper_owner_agents(T, N, (T + 1 <= 32 && N <= 32) ? 32 : 64) < N) { o += 4 * T; L.part = o; o += kPart * T; }
+  if (kind != kLayoutStage && helper_owner_agents(T, N, W) < N) { o += 4 * T; L.part = o; o += kPart * T; }
   L.lanec = o; o += 3 * T;
   L.lm = o; if (with_lm) o += P * P + 6 * P + 24;  // Hs, six vectors, scalars: what lives from trip to trip
   L.gram = o; o += (P + 1) * (P + 1);  // dense symmetric [J r]^T [J r] of the latest sweep (VALU back-end)

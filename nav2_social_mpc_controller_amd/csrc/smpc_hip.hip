@@ -176,8 +176,7 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
   k->dt = sb->dt; k->resolution = sb->resolution; k->inv_resolution = 1.0 / sb->resolution;
   k->prm = h->prm;
   k->e_M = d.M;
-  k->hp_A = smpc::helper_owner_agents(sb->T, sb->N, smpc::slot_width(sb->T, sb->N));
-  if (std::getenv("SMPC_NO_HELPERS")) k->hp_A = sb->N;  // experiment knob (the LDS layout keeps the helper regions)
+  k->hp_A = sb->N;  // set by launch() once the slot width is chosen
   smpc::fill_math_table(&k->mt);
 }
 
@@ -249,7 +248,7 @@ int launch_stage(smpc_handle* h, smpc::KParams& k, double* rec, double* aux) {
   if (k.B == 0 || k.N == 0) return SMPC_OK;
   const int W = smpc::slot_width(k.T, k.N);
   const int S = smpc::kWave / W;
-  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, 2, smpc::kLayoutStage);
+  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, 2, smpc::kLayoutStage, W);
   const size_t shmem = (size_t)S * L.total * sizeof(double);
   KernelFn fn = (W == 32) ? smpc::smpc_stage_kernel<32> : smpc::smpc_stage_kernel<64>;
   if (shmem > 160 * 1024) { set_error("people block does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
@@ -278,11 +277,39 @@ int bind_people(smpc_handle* h, const smpc_scene_batch* sb, smpc::KParams& k, St
   return SMPC_OK;
 }
 
-int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
+// Waves per CU a solve launch takes when it is sized for having the GPU to itself (launch(), below).
+int lone_waves_per_cu() {
+  int lone_per_cu = 8;
+  if (const char* v = std::getenv("SMPC_LONE_WAVES_PER_CU")) { const int c = std::atoi(v); if (c >= 1) lone_per_cu = c; }  // experiment knob
+  return lone_per_cu;
+}
+
+// Slot width of a solve launch. A shape that fits two scenes per wave (W = 32) still runs ONE scene per wave while the
+// batch is small: up to one scene per SIMD (4 x CUs), two scenes in the lockstep of one wave only make each other wait
+// (their LM phases differ from trip to trip; measured 4-17 % slower than a wave each, with bit-identical results); and
+// where the W = 64 kernel's helper lanes pay (helper_owner_agents(): the 64 - T lanes beyond the horizon take over half
+// of every step's agent list), up to the number of waves a lone launch takes anyway (8 per CU): every sweep of every
+// scene is shorter then — the plugin's own call (B = 1, 8 people) 1.24 -> 1.06 ms, 1024 scenes 1.60 -> 1.13 ms, equal at
+// 2048 (tools/gpu_width.py). Decided by the shape of the batch alone (B, T, N, the handle's share): a scene's result
+// never depends on timing. With helper lanes it differs from the W = 32 kernel's in the last bits (the order of the
+// sums over the agents).
+int solve_slot_width(const smpc_handle* h, const smpc::KParams& k) {
   const int W = smpc::slot_width(k.T, k.N);
+  if (W == 64) return 64;
+  if (const char* v = std::getenv("SMPC_SOLVE_WIDTH")) { const int c = std::atoi(v); if (c == 32 || c == 64) return c; }  // experiment knob
+  const int share = h->share > 1 ? h->share : 1;
+  const bool helpers_pay = smpc::helper_owner_agents(k.T, k.N, 64) < k.N;
+  const int per_cu = helpers_pay ? lone_waves_per_cu() : 4;
+  return (k.B <= per_cu * h->num_cu / share) ? 64 : 32;
+}
+
+int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
+  const int W = eval ? smpc::slot_width(k.T, k.N) : solve_slot_width(h, k);
   const int S = smpc::kWave / W;
   KernelFn fn = pick(k.nb, W, eval, k.T_scene != nullptr);
-  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve);
+  const smpc::LdsLayout L = smpc::make_layout(k.T, k.N, k.P, eval ? smpc::kLayoutEval : smpc::kLayoutSolve, W);
+  k.hp_A = smpc::helper_owner_agents(k.T, k.N, W);
+  if (std::getenv("SMPC_NO_HELPERS")) k.hp_A = k.N;  // experiment knob (the LDS layout keeps the helper regions)
   // behind the slot blocks: the feasibility rows of every slot (solve) or the row staging blocks + parked sensitivities (K1)
   const size_t extra = eval ? (size_t)smpc::eval_extra_doubles(k.T, k.P, W) : (size_t)smpc::wave_extra_doubles(k.P, W);
   const size_t shmem = ((size_t)S * L.total + extra) * sizeof(double);
@@ -306,8 +333,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     // a third wave per SIMD lengthens every trip more than it shortens the queue, and the tail of long scenes grows);
     // the third wave's registers and LDS then stay free for the launches of other streams, which is where the extra
     // occupancy pays. Only a batch with many scenes per slot takes every resident wave for itself.
-    int lone_per_cu = 8;
-    if (const char* v = std::getenv("SMPC_LONE_WAVES_PER_CU")) { const int c = std::atoi(v); if (c >= 1) lone_per_cu = c; }  // experiment knob
+    const int lone_per_cu = lone_waves_per_cu();
     const int two_per_simd = lone_per_cu * h->num_cu < resident ? lone_per_cu * h->num_cu : resident;
     if (grid > two_per_simd) grid = (grid >= 4 * resident) ? resident : two_per_simd;
     k.queue = h->queue;
@@ -481,6 +507,14 @@ int smpc_set_solve_share(smpc_handle* h, int32_t n) {
   if (!h || n < 1) { set_error("null handle or share < 1"); return SMPC_ERR_INVALID_ARG; }
   h->share = n;
   return SMPC_OK;
+}
+
+int smpc_solve_slot_width(const smpc_handle* h, int32_t B, int32_t T, int32_t N) {
+  if (!h || B < 0 || T < 1 || N < 0) { set_error("null handle or bad B/T/N"); return SMPC_ERR_INVALID_ARG; }
+  if (T + 1 > smpc::kWave || N > smpc::kWave) { set_error("T + 1 > 64 rollout poses or N > 64 agents"); return SMPC_ERR_UNSUPPORTED; }
+  smpc::KParams k;
+  k.B = B; k.T = T; k.N = N;
+  return solve_slot_width(h, k);
 }
 
 int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_batch* out) {

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
   const int lane = threadIdx.x & 63;
   Ctx c;
   c.kp = &k;
-  c.L = make_layout(k.T, k.N, P, kLayoutSolve);
+  c.L = make_layout(k.T, k.N, P, kLayoutSolve, W);
   c.ag = k.people_rec;
   const auto& prm = k.prm;
   const int T = k.T;
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES(NB)) void smpc_eval_kernel(
   Ctx c;
   c.kp = &k;
   c.sl = lane - slot * W;
-  c.L = make_layout(k.T, k.N, P, kLayoutEval);
+  c.L = make_layout(k.T, k.N, P, kLayoutEval, W);
   c.lds = lds_all + (size_t)slot * c.L.total;
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(64) void smpc_stage_kernel(const KParams) {
   const int lane = threadIdx.x & 63;
   const int slot = lane / W, sl = lane - slot * W;
   const int T = k.T, N = k.N;
-  const LdsLayout L = make_layout(T, N, 2, kLayoutStage);
+  const LdsLayout L = make_layout(T, N, 2, kLayoutStage, W);
   double* lds = lds_all + (size_t)slot * L.total;
   const int scene_raw = blockIdx.x * S + slot;
   const bool live = scene_raw < k.B;

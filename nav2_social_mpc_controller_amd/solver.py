@@ -56,6 +56,8 @@ def load_library():
     lib.smpc_set_stream.restype = C.c_int
     lib.smpc_set_solve_share.argtypes = [C.c_void_p, C.c_int32]
     lib.smpc_set_solve_share.restype = C.c_int
+    lib.smpc_solve_slot_width.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.smpc_solve_slot_width.restype = C.c_int
     lib.smpc_solve_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.POINTER(SmpcResultBatch)]
     lib.smpc_solve_batch.restype = C.c_int
     lib.smpc_eval_batch.argtypes = [C.c_void_p, C.POINTER(SmpcSceneBatch), C.c_void_p, C.POINTER(SmpcEvalOut)]
@@ -123,6 +125,13 @@ class BatchSolver:
     def set_solve_share(self, n: int):
         """smpc_set_solve_share: this handle's solve launches leave room for n - 1 concurrent ones (other streams)."""
         _check(self.lib, self.lib.smpc_set_solve_share(self._h, int(n)), "smpc_set_solve_share")
+
+    def solve_slot_width(self, B: int, T: int, N: int) -> int:
+        """smpc_solve_slot_width: 32 (two scenes per wave) or 64 (one) for a solve launch of this shape."""
+        w = self.lib.smpc_solve_slot_width(self._h, int(B), int(T), int(N))
+        if w < 0:
+            _check(self.lib, w, "smpc_solve_slot_width")
+        return w
 
     def math_probe(self, fn: int, a: np.ndarray, b: np.ndarray = None):
         """smpc_math_probe: the sweep's elementary functions evaluated on the device (see include/smpc.h)."""

@@ -83,3 +83,26 @@ def test_solve_share_changes_the_grid_not_the_results():
             assert np.array_equal(base[k], got[k]), (n, k)
     with pytest.raises(SmpcError):
         s.set_solve_share(0)
+
+
+@pytest.mark.gpu
+def test_solve_slot_width_rule():
+    """smpc_solve_slot_width: one scene per wave for every shape beyond 31 steps / 32 agents, and for the shapes that fit
+    two per wave while the batch is small (one scene per SIMD; eight waves per CU where helper lanes pay); a function of
+    the batch's shape and the handle's share alone."""
+    from nav2_social_mpc_controller_amd.solver import BatchSolver, SmpcError
+
+    s = BatchSolver(OptimizerParams.readme())
+    cus = 256  # MI355X
+    assert s.solve_slot_width(8192, 38, 16) == 64 and s.solve_slot_width(1, 38, 3) == 64
+    assert s.solve_slot_width(8192, 28, 64) == 64
+    assert s.solve_slot_width(8192, 28, 8) == 32
+    assert s.solve_slot_width(1, 28, 8) == 64 and s.solve_slot_width(8 * cus, 28, 8) == 64
+    assert s.solve_slot_width(8 * cus + 1, 28, 8) == 32
+    assert s.solve_slot_width(4 * cus, 28, 3) == 64 and s.solve_slot_width(4 * cus + 1, 28, 3) == 32
+    assert s.solve_slot_width(4 * cus, 28, 0) == 64
+    s.set_solve_share(3)
+    assert s.solve_slot_width(8 * cus // 3, 28, 8) == 64 and s.solve_slot_width(8 * cus // 3 + 1, 28, 8) == 32
+    s.set_solve_share(1)
+    with pytest.raises(SmpcError):
+        s.solve_slot_width(1, 64, 3)

@@ -135,6 +135,44 @@ SOLVE_CASES = {
 
 @pytest.mark.parametrize("name", list(SOLVE_CASES))
 def test_solve_matches_oracle_on_seeded_scenes(Solver, oracle, name):
+    check_solve_case(Solver, oracle, name)
+
+
+# Batches this small run one scene per wave (the W = 64 kernel, helper lanes from four people up: solve_slot_width() in
+# csrc/smpc_hip.hip); the two-scenes-per-wave kernel that the large batches of the same shapes take is put through the
+# same cases here (SMPC_SOLVE_WIDTH is read at every launch), next to the full-size tests below.
+TWO_SLOT_CASES = ["cfg2_n4", "cfg3_n8", "single_block", "w32_five_blocks_valu_gram", "t31_last_two_slot_shape",
+                  "n32_last_two_slot_shape"]
+
+
+@pytest.mark.parametrize("name", TWO_SLOT_CASES)
+def test_solve_matches_oracle_two_scenes_per_wave(Solver, oracle, name, monkeypatch):
+    monkeypatch.setenv("SMPC_SOLVE_WIDTH", "32")
+    check_solve_case(Solver, oracle, name)
+
+
+def test_slot_widths_agree(Solver, monkeypatch):
+    """One scene per wave against two: bit-identical without helper lanes (three people: the same sums in the same
+    order), the same LM path with them (eight people: the sums over the agents are split between owner and helper)."""
+    for N, exact in ((3, True), (8, False)):
+        sc = make_scenes(README, 256, N, seed=0x51D7 + N)
+        res = {}
+        for width in ("32", "64"):
+            monkeypatch.setenv("SMPC_SOLVE_WIDTH", width)
+            res[width] = Solver(README).solve(sc)
+        a, b = res["32"], res["64"]
+        if exact:
+            for key in ("cmds", "path", "params", "final_cost", "iterations", "evaluations", "status"):
+                assert np.array_equal(a[key], b[key]), key
+        else:
+            same = (a["iterations"] == b["iterations"]) & (a["evaluations"] == b["evaluations"])
+            assert same.mean() >= 0.98
+            d = cmd_err(a["cmds"], b["cmds"])
+            assert np.median(d) <= 1e-13 and np.max(d[same]) <= 1e-6
+            assert np.array_equal(a["status"], b["status"])
+
+
+def check_solve_case(Solver, oracle, name):
     prm, kw = SOLVE_CASES[name]
     sc = make_scenes(prm, **kw)
     rg = Solver(prm).solve(sc)
