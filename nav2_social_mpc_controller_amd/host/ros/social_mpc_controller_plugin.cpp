@@ -9,8 +9,10 @@
 #include "social_mpc_controller_plugin.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <stdexcept>
 #include <utility>
+#include <vector>
 
 #include "nav2_core/exceptions.hpp"
 #include "nav2_util/node_utils.hpp"
