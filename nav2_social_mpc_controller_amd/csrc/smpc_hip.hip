@@ -7,6 +7,7 @@
 //   smpc_eval_kernel<NB,W>   K1: one residual + Jacobian sweep, rows written to HBM (parity + roofline runs).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -117,6 +118,8 @@ struct smpc_handle {
   char* stage;        // grow-only arena for host-pointer calls (the plugin's B = 1 use): no hipMalloc per call
   size_t stage_cap;
   size_t stage_want;  // high-water mark of the calls so far
+  char* pin;          // page-locked host mirror of the arena's first pin_cap bytes: the small arrays of a host-pointer call
+  size_t pin_cap;     // travel in ONE copy each way instead of one pageable hipMemcpy per array (Staging, below)
 };
 
 namespace {
@@ -185,9 +188,18 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
 // Host-pointer batches are staged through device memory by this helper: sub-allocations of the handle's arena, which
 // grows to the high-water mark at the start of the next call (every host-pointer call ends with a stream synchronise,
 // so nothing is in flight then); what does not fit meanwhile comes from hipMalloc and is freed when the call returns.
+// The plugin's own call (B = 1: a dozen arrays of a few hundred bytes and one costmap) used to spend more time in its 16
+// pageable hipMemcpy calls than in its kernels. The head of the arena (kPinBytes) therefore has a page-locked mirror on
+// the host: inputs that land there are gathered in the mirror and cross in ONE asynchronous copy (flush_up(), before the
+// first kernel of the call), outputs that land there come back in one copy and are handed out from the mirror
+// (finish()). What lies beyond the mirror (large batches) is copied array by array as before.
+constexpr size_t kPinBytes = 8u << 20;
 struct Staging {
   smpc_handle* h;
   size_t off = 0, need = 0;
+  size_t up_lo = SIZE_MAX, up_hi = 0;  // arena bytes [up_lo, up_hi) wait in the mirror for flush_up()
+  struct Deferred { void* host; size_t off, bytes; };
+  std::vector<Deferred> downs;         // outputs inside the mirrored range: fetched by finish()
   std::vector<void*> overflow;
   explicit Staging(smpc_handle* handle) : h(handle) {
     if (h && h->stage_want > h->stage_cap) {
@@ -196,6 +208,15 @@ struct Staging {
       const size_t cap = h->stage_want + h->stage_want / 4;
       void* p = nullptr;
       if (hipMalloc(&p, cap) == hipSuccess) { h->stage = static_cast<char*>(p); h->stage_cap = cap; }
+    }
+    if (h && h->stage) {
+      const size_t want = h->stage_cap < kPinBytes ? h->stage_cap : kPinBytes;
+      if (h->pin_cap < want) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        h->pin = nullptr; h->pin_cap = 0;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) == hipSuccess) { h->pin = static_cast<char*>(p); h->pin_cap = want; }
+      }
     }
   }
   ~Staging() {
@@ -212,13 +233,33 @@ struct Staging {
     *out = p;
     return SMPC_OK;
   }
+  // offset of a device pointer inside the mirrored head of the arena, or SIZE_MAX
+  size_t mirrored(const void* dev, size_t bytes) const {
+    if (!h || !h->stage || !h->pin) return SIZE_MAX;
+    const char* p = static_cast<const char*>(dev);
+    if (p < h->stage || p + bytes > h->stage + h->pin_cap) return SIZE_MAX;
+    return (size_t)(p - h->stage);
+  }
   template <typename T> int up(const T* host, size_t n, const T** dev, hipStream_t st) {
     *dev = nullptr;
     if (!host || n == 0) return SMPC_OK;
     void* p = nullptr;
     SMPC_TRY_(take(n * sizeof(T), &p));
-    SMPC_HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, st));
+    const size_t o = mirrored(p, n * sizeof(T));
+    if (o != SIZE_MAX) {
+      std::memcpy(h->pin + o, host, n * sizeof(T));
+      if (o < up_lo) up_lo = o;
+      if (o + n * sizeof(T) > up_hi) up_hi = o + n * sizeof(T);
+    } else {
+      SMPC_HIP_CHECK(hipMemcpyAsync(p, host, n * sizeof(T), hipMemcpyHostToDevice, st));
+    }
     *dev = static_cast<const T*>(p);
+    return SMPC_OK;
+  }
+  // the gathered inputs cross here: every entry point calls it before its first kernel launch
+  int flush_up(hipStream_t st) {
+    if (up_hi > up_lo) SMPC_HIP_CHECK(hipMemcpyAsync(h->stage + up_lo, h->pin + up_lo, up_hi - up_lo, hipMemcpyHostToDevice, st));
+    up_lo = SIZE_MAX; up_hi = 0;
     return SMPC_OK;
   }
   template <typename T> int out(T* host, size_t n, T** dev) {
@@ -227,6 +268,26 @@ struct Staging {
     void* p = nullptr;
     SMPC_TRY_(take(n * sizeof(T), &p));
     *dev = static_cast<T*>(p);
+    return SMPC_OK;
+  }
+  template <typename T> int down(T* host, const T* dev, size_t n, hipStream_t st) {
+    if (!host || !dev || n == 0) return SMPC_OK;
+    const size_t o = mirrored(dev, n * sizeof(T));
+    if (o != SIZE_MAX) { downs.push_back({host, o, n * sizeof(T)}); return SMPC_OK; }
+    SMPC_HIP_CHECK(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, st));
+    return SMPC_OK;
+  }
+  // end of a host-pointer call: the deferred outputs in one copy, the stream drained, the results handed out
+  int finish(hipStream_t st) {
+    if (up_hi > up_lo) SMPC_TRY_(flush_up(st));  // a call that launched nothing (empty batch)
+    if (!downs.empty()) {
+      size_t lo = SIZE_MAX, hi = 0;
+      for (const Deferred& d : downs) { if (d.off < lo) lo = d.off; if (d.off + d.bytes > hi) hi = d.off + d.bytes; }
+      SMPC_HIP_CHECK(hipMemcpyAsync(h->pin + lo, h->stage + lo, hi - lo, hipMemcpyDeviceToHost, st));
+    }
+    SMPC_HIP_CHECK(hipStreamSynchronize(st));
+    for (const Deferred& d : downs) std::memcpy(d.host, h->pin + d.off, d.bytes);
+    downs.clear();
     return SMPC_OK;
   }
 };
@@ -272,6 +333,7 @@ int bind_people(smpc_handle* h, const smpc_scene_batch* sb, smpc::KParams& k, St
   }
   SMPC_TRY_(grow(&h->stage_rec, &h->stage_rec_bytes, nrec * sizeof(double), h->stream));
   SMPC_TRY_(grow(&h->stage_aux, &h->stage_aux_bytes, naux * sizeof(double), h->stream));
+  SMPC_TRY_(st->flush_up(h->stream));
   SMPC_TRY_(launch_stage(h, k, h->stage_rec, h->stage_aux));
   k.people_rec = h->stage_rec; k.people_aux = h->stage_aux;
   return SMPC_OK;
@@ -402,12 +464,6 @@ int bind_inputs(smpc_handle* h, const smpc_scene_batch* sb, const Dims& d, smpc:
   return SMPC_OK;
 }
 
-template <typename T> int down(T* host, const T* dev, size_t n, hipStream_t st) {
-  if (!host || !dev || n == 0) return SMPC_OK;
-  SMPC_HIP_CHECK(hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, st));
-  return SMPC_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -470,6 +526,8 @@ smpc_handle* smpc_create(const smpc_params* p, int device) {
   h->stage = nullptr;
   h->stage_cap = 0;
   h->stage_want = 0;
+  h->pin = nullptr;
+  h->pin_cap = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); delete h; return nullptr; }
   h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -486,6 +544,7 @@ void smpc_destroy(smpc_handle* h) {
   if (h->stage_rec) (void)hipFree(h->stage_rec);
   if (h->stage_aux) (void)hipFree(h->stage_aux);
   if (h->stage) (void)hipFree(h->stage);
+  if (h->pin) (void)hipHostFree(h->pin);
   delete h;
 }
 
@@ -558,17 +617,18 @@ int smpc_solve_batch(smpc_handle* h, const smpc_scene_batch* sb, smpc_result_bat
   SMPC_TRY(st.out(out->evaluations, B, &k.o_evaluations));
   SMPC_TRY(st.out(out->initial_cost, B, &k.o_initial_cost));
   SMPC_TRY(st.out(out->final_cost, B, &k.o_final_cost));
+  SMPC_TRY(st.flush_up(h->stream));
   SMPC_TRY(launch(h, false, k));
-  SMPC_TRY(down(out->params, k.o_params, B * d.P, h->stream));
-  SMPC_TRY(down(out->cmds, k.o_cmds, B * (T + 1) * 2, h->stream));
-  SMPC_TRY(down(out->path, k.o_path, B * (T + 1) * 3, h->stream));
-  SMPC_TRY(down(out->status, k.o_status, B, h->stream));
-  SMPC_TRY(down(out->reason, k.o_reason, B, h->stream));
-  SMPC_TRY(down(out->iterations, k.o_iterations, B, h->stream));
-  SMPC_TRY(down(out->evaluations, k.o_evaluations, B, h->stream));
-  SMPC_TRY(down(out->initial_cost, k.o_initial_cost, B, h->stream));
-  SMPC_TRY(down(out->final_cost, k.o_final_cost, B, h->stream));
-  SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  SMPC_TRY(st.down(out->params, k.o_params, B * d.P, h->stream));
+  SMPC_TRY(st.down(out->cmds, k.o_cmds, B * (T + 1) * 2, h->stream));
+  SMPC_TRY(st.down(out->path, k.o_path, B * (T + 1) * 3, h->stream));
+  SMPC_TRY(st.down(out->status, k.o_status, B, h->stream));
+  SMPC_TRY(st.down(out->reason, k.o_reason, B, h->stream));
+  SMPC_TRY(st.down(out->iterations, k.o_iterations, B, h->stream));
+  SMPC_TRY(st.down(out->evaluations, k.o_evaluations, B, h->stream));
+  SMPC_TRY(st.down(out->initial_cost, k.o_initial_cost, B, h->stream));
+  SMPC_TRY(st.down(out->final_cost, k.o_final_cost, B, h->stream));
+  SMPC_TRY(st.finish(h->stream));
   return SMPC_OK;
 }
 
@@ -610,15 +670,16 @@ int smpc_project_people_batch(smpc_handle* h, const smpc_projection_batch* in, d
     const int per_wave = smpc::kWave / (G * p.H);
     const int grid = (int)((B + per_wave - 1) / per_wave);
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_project_kernel, dim3(grid), dim3(smpc::kWave), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
   }
   if (!in->on_device) {
-    SMPC_TRY(down(people_proj, p.people_proj, B * (T + 1) * 6 * N, h->stream));
-    SMPC_TRY(down(error, p.error, B, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(people_proj, p.people_proj, B * (T + 1) * 6 * N, h->stream));
+    SMPC_TRY(st.down(error, p.error, B, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -654,15 +715,16 @@ int smpc_people_to_status_batch(smpc_handle* h, const smpc_people_batch* in, dou
   }
   if (B > 0) {
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_people_to_status_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
   }
   if (!in->on_device) {
-    SMPC_TRY(down(init_people, p.init_people, B * N * 6, h->stream));
-    SMPC_TRY(down(has_people, p.has_people, B, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(init_people, p.init_people, B * N * 6, h->stream));
+    SMPC_TRY(st.down(has_people, p.has_people, B, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -715,6 +777,7 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
   if (B > 0) {
     const long long n = (long long)B * (long long)Tp;
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_format_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(smpc::smpc_format_mark_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, p);
@@ -723,17 +786,17 @@ int smpc_format_to_optimize_batch(smpc_handle* h, const smpc_format_batch* in, s
     h->timed = true;
   }
   if (!in->on_device) {
-    SMPC_TRY(down(out->robot_status, p.robot_status, B * Tp * 6, h->stream));
-    SMPC_TRY(down(out->pose0, p.pose0, B * 3, h->stream));
-    SMPC_TRY(down(out->init_params, p.init_params, B * (size_t)d.P, h->stream));
-    SMPC_TRY(down(out->path_pts, p.path_pts, B * Tp * 2, h->stream));
-    SMPC_TRY(down(out->goal_yaw, p.goal_yaw, B, h->stream));
-    SMPC_TRY(down(in->memory.prev_path, p.prev_path, B * Tp * 3, h->stream));
-    SMPC_TRY(down(in->memory.prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
-    SMPC_TRY(down(in->memory.valid, p.valid, B, h->stream));
-    SMPC_TRY(down(in->memory.length, p.length, B * 2, h->stream));
-    SMPC_TRY(down(out->T_scene, p.T_scene, B, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(out->robot_status, p.robot_status, B * Tp * 6, h->stream));
+    SMPC_TRY(st.down(out->pose0, p.pose0, B * 3, h->stream));
+    SMPC_TRY(st.down(out->init_params, p.init_params, B * (size_t)d.P, h->stream));
+    SMPC_TRY(st.down(out->path_pts, p.path_pts, B * Tp * 2, h->stream));
+    SMPC_TRY(st.down(out->goal_yaw, p.goal_yaw, B, h->stream));
+    SMPC_TRY(st.down(in->memory.prev_path, p.prev_path, B * Tp * 3, h->stream));
+    SMPC_TRY(st.down(in->memory.prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
+    SMPC_TRY(st.down(in->memory.valid, p.valid, B, h->stream));
+    SMPC_TRY(st.down(in->memory.length, p.length, B * 2, h->stream));
+    SMPC_TRY(st.down(out->T_scene, p.T_scene, B, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -770,17 +833,18 @@ int smpc_memory_store_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t on_de
   if (B > 0) {
     const long long n = (long long)B * (long long)Tp;
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_memory_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
   }
   if (!on_device) {
-    SMPC_TRY(down(memory->prev_path, p.prev_path, B * Tp * 3, h->stream));
-    SMPC_TRY(down(memory->prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
-    SMPC_TRY(down(memory->valid, p.valid, B, h->stream));
-    SMPC_TRY(down(memory->length, p.length, B * 2, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(memory->prev_path, p.prev_path, B * Tp * 3, h->stream));
+    SMPC_TRY(st.down(memory->prev_cmds, p.prev_cmds, B * Tp * 2, h->stream));
+    SMPC_TRY(st.down(memory->valid, p.valid, B, h->stream));
+    SMPC_TRY(st.down(memory->length, p.length, B * 2, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -824,6 +888,7 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
     const size_t park = park_wave * (threads / smpc::kWave);
     const dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(threads);
     const int need = (int)((L + smpc::kTrajGroup - 1) / smpc::kTrajGroup);
+    SMPC_TRY(st.flush_up(h->stream));
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
     // plans over 512 poses: one-wavefront blocks of the 8-slot kernel with the reachable poses compacted into LDS
     const size_t list_wave = (size_t)per_wave * 8 * smpc::kTrajGroup * 2 * sizeof(double);
@@ -847,12 +912,12 @@ int smpc_trajectorize_path_batch(smpc_handle* h, const smpc_trajectorize_batch* 
     h->timed = true;
   }
   if (!in->on_device) {
-    SMPC_TRY(down(out->path, p.path, B * S1 * 3, h->stream));
-    SMPC_TRY(down(out->cmds, p.cmds, B * S1 * 2, h->stream));
-    SMPC_TRY(down(out->cmds_vy, p.cmds_vy, B * S1, h->stream));
-    SMPC_TRY(down(out->n_poses, p.n_poses, B, h->stream));
-    SMPC_TRY(down(out->error, p.error, B, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(out->path, p.path, B * S1 * 3, h->stream));
+    SMPC_TRY(st.down(out->cmds, p.cmds, B * S1 * 2, h->stream));
+    SMPC_TRY(st.down(out->cmds_vy, p.cmds_vy, B * S1, h->stream));
+    SMPC_TRY(st.down(out->n_poses, p.n_poses, B, h->stream));
+    SMPC_TRY(st.down(out->error, p.error, B, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -885,17 +950,18 @@ int smpc_transform_global_plan_batch(smpc_handle* h, const smpc_plan_window_batc
   }
   if (B > 0) {
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_plan_window_kernel, dim3((unsigned)B), dim3(smpc::kWave), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
   }
   if (!in->on_device) {
-    SMPC_TRY(down(window, p.window, B * L * 2, h->stream));
-    SMPC_TRY(down(window_len, p.window_len, B, h->stream));
-    SMPC_TRY(down(in->plan_start, static_cast<const int32_t*>(p.plan_start), B, h->stream));
-    SMPC_TRY(down(error, p.error, B, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(window, p.window, B * L * 2, h->stream));
+    SMPC_TRY(st.down(window_len, p.window_len, B, h->stream));
+    SMPC_TRY(st.down(in->plan_start, static_cast<const int32_t*>(p.plan_start), B, h->stream));
+    SMPC_TRY(st.down(error, p.error, B, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -925,15 +991,16 @@ int smpc_select_command_batch(smpc_handle* h, int32_t B_, int32_t T, int32_t tra
   }
   if (B > 0) {
     SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_select_command_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
     SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
     h->timed = true;
   }
   if (!on_device) {
-    SMPC_TRY(down(cmd_vel, p.cmd_vel, B * 2, h->stream));
-    SMPC_TRY(down(source, p.source, B, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(cmd_vel, p.cmd_vel, B * 2, h->stream));
+    SMPC_TRY(st.down(source, p.source, B, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -964,13 +1031,14 @@ int smpc_stage_people_batch(smpc_handle* h, const smpc_scene_batch* sb, double* 
     SMPC_HIP_CHECK(hipMemsetAsync(daux, 0, naux * sizeof(double), h->stream));
   }
   SMPC_HIP_CHECK(hipEventRecord(h->ev0, h->stream));
+  SMPC_TRY(st.flush_up(h->stream));
   SMPC_TRY(launch_stage(h, k, drec, daux));
   SMPC_HIP_CHECK(hipEventRecord(h->ev1, h->stream));
   h->timed = true;
   if (!sb->on_device) {
-    SMPC_TRY(down(records, drec, nrec, h->stream));
-    SMPC_TRY(down(aux, daux, naux, h->stream));
-    SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+    SMPC_TRY(st.down(records, drec, nrec, h->stream));
+    SMPC_TRY(st.down(aux, daux, naux, h->stream));
+    SMPC_TRY(st.finish(h->stream));
   }
   return SMPC_OK;
 }
@@ -1012,12 +1080,13 @@ int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, cons
   SMPC_TRY(st.out(out0, (size_t)n, &p.o0));
   SMPC_TRY(st.out(out1, (size_t)n, &p.o1));
   if (n > 0) {
+    SMPC_TRY(st.flush_up(h->stream));
     hipLaunchKernelGGL(smpc::smpc_math_probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, p);
     SMPC_HIP_CHECK(hipGetLastError());
   }
-  SMPC_TRY(down(out0, p.o0, (size_t)n, h->stream));
-  SMPC_TRY(down(out1, p.o1, (size_t)n, h->stream));
-  SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  SMPC_TRY(st.down(out0, p.o0, (size_t)n, h->stream));
+  SMPC_TRY(st.down(out1, p.o1, (size_t)n, h->stream));
+  SMPC_TRY(st.finish(h->stream));
   return SMPC_OK;
 }
 
@@ -1045,12 +1114,13 @@ int smpc_eval_batch(smpc_handle* h, const smpc_scene_batch* sb, const double* pa
   SMPC_TRY(st.out(out->jacobian, B * d.M * d.P, &k.e_jacobian));
   SMPC_TRY(st.out(out->cost, B, &k.e_cost));
   SMPC_TRY(st.out(out->gradient, B * d.P, &k.e_gradient));
+  SMPC_TRY(st.flush_up(h->stream));
   SMPC_TRY(launch(h, true, k));
-  SMPC_TRY(down(out->residuals, k.e_residuals, B * d.M, h->stream));
-  SMPC_TRY(down(out->jacobian, k.e_jacobian, B * d.M * d.P, h->stream));
-  SMPC_TRY(down(out->cost, k.e_cost, B, h->stream));
-  SMPC_TRY(down(out->gradient, k.e_gradient, B * d.P, h->stream));
-  SMPC_HIP_CHECK(hipStreamSynchronize(h->stream));
+  SMPC_TRY(st.down(out->residuals, k.e_residuals, B * d.M, h->stream));
+  SMPC_TRY(st.down(out->jacobian, k.e_jacobian, B * d.M * d.P, h->stream));
+  SMPC_TRY(st.down(out->cost, k.e_cost, B, h->stream));
+  SMPC_TRY(st.down(out->gradient, k.e_gradient, B * d.P, h->stream));
+  SMPC_TRY(st.finish(h->stream));
   return SMPC_OK;
 }
 
