@@ -442,7 +442,8 @@ int smpc_select_command_batch(smpc_handle* h, int32_t B, int32_t T, int32_t traj
  * sincos, refined reciprocal / rsqrt, and the raw hardware estimates behind them) on n host-side arguments, so that
  * tests can check them on the device against libm. fn: 0 exp(a) | 1 atan2(a, b) | 2 sin(a) -> out0, cos(a) -> out1 |
  * 3 1/sqrt(a) | 4 a / b | 5 raw v_rcp_f64(a) | 6 raw v_rsq_f64(a) | 7 the line search's bracketed root finder on n
- * quartics (a holds 8 doubles per problem: c4 c3 c2 c1 c0 lo hi pad; root -> out0, loop trips -> out1).
+ * quartics (a holds 8 doubles per problem: c4 c3 c2 c1 c0 lo hi pad; root -> out0, loop trips -> out1) | 8 atan2(a, b)
+ * of a unit vector (the social force's angle: node table in LDS, no division).
  * out1 may be NULL unless fn == 2 or 7. */
 int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1);
 

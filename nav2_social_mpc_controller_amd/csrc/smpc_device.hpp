@@ -72,6 +72,7 @@ struct KParams {
   int e_M;  // row stride of the eval outputs (M with people)
   int e_row_order;  // 0: reference (step-major) row order, 1: critic-major (smpc_eval_batch_out.row_order)
   MathTab mt;  // polynomial coefficients of smpc_math.hpp, read through scalar loads
+  AtanNodeTab an;  // nodes of atan2_unit(), copied into LDS by every wave (load_atan_nodes)
 };
 
 // Cross-lane sum of the per-lane Gram shares (solve kernel): values go through LDS in chunks of whole columns of the
@@ -85,6 +86,9 @@ constexpr int kSensInRegsMaxBlocks = 6;  // K1 keeps a lane's sensitivities in r
 __host__ __device__ constexpr int eval_extra_doubles(int T, int P, int W) {
   return (64 / W) * (2 * T * P) + (P / 2 > kSensInRegsMaxBlocks ? (64 / W) * (5 * (P / 2) * W) : 0);
 }
+// The node table of atan2_unit() sits behind everything else in a wave's LDS (solve and K1 kernels).
+__host__ __device__ constexpr int atan_tab_offset(int slot_doubles, int extra_doubles) { return (slot_doubles + extra_doubles + 3) & ~3; }
+constexpr int kAtanTabDoubles = kAtanNodes * kAtanNodeStride;
 constexpr int kGramChunk = 16;
 __host__ __device__ constexpr int gram_red_doubles(int W) { return W * (kGramChunk + 1); }
 // doubles of wave-shared LDS behind the per-slot blocks of the solve kernel: the feasibility rows of every slot
@@ -311,7 +315,7 @@ __device__ inline Force social_force_general(double dx, double dy, double ux, do
 // to every pair: the force and its diff-derivatives come WITHOUT the factor k (kPairForceK), the u-derivatives without
 // k * lambda (kPairForceLambda; u enters the interaction vector as lambda u).
 constexpr double kPairForceK = 2.1, kPairForceLambda = 2.0;
-__device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux, double uy) {
+__device__ inline Force pair_force(MathTabP mt, const double* atab, double dx, double dy, double ux, double uy) {
   const double lambda = kPairForceLambda, gamma = 0.35, nPrime = 3.0, nn = 2.0;
   Force R;
   const double d2 = fma(dx, dx, dy * dy);
@@ -325,7 +329,7 @@ __device__ inline Force pair_force(MathTabP mt, double dx, double dy, double ux,
   const double ix = ivx * inv_L, iy = ivy * inv_L;  // :195-196
   const double cross = fma(ix, ey, -(iy * ex)), dot = fma(ix, ex, iy * ey);
   const bool zero_u = (ux == 0.0) & (uy == 0.0);  // equal velocities: theta := 0 (parity)
-  double phi = atan2_dir(mt, cross, dot);
+  double phi = atan2_unit(mt, atab, cross, dot);  // (cross, dot) = (sin, cos) of theta: a unit vector
   // keep the scheduler from interleaving the arctangent, the two exponentials and the derivative block: the extra
   // overlap buys nothing with two or three waves per SIMD and costs ~15 VGPRs (the stand-alone K1 kernel would drop
   // from three waves per SIMD to two)
@@ -508,12 +512,19 @@ struct Ctx {
   int sl;      // lane within the slot = horizon step owned by this lane (per-lane)
   int slot;
   bool has_people;
+  bool gram_full;  // solve kernel: the latest sweep left the whole Gram in LDS, not only its last column (wave-uniform)
   const uint8_t* map;
   double* lds;       // this slot's LDS block (scene constants, cos/sin block, LM state live here)
   const double* ag;  // staged people records [N][T][4] of this slot's scene (global memory)
   double* wave_lds;  // wave-shared LDS behind the slot blocks (solve: feasibility rows of every slot; K1: row staging blocks)
+  const double* atab;  // the wave's copy of the atan2_unit() nodes (LDS)
   LdsLayout L;
 };
+
+// every lane of the wave; the caller fences before the first sweep
+__device__ inline void load_atan_nodes(KParamsK kp, double* dst, int lane) {
+  for (int i = lane; i < kAtanTabDoubles; i += kWave) dst[i] = kp->an.v[i];
+}
 
 // Dense symmetric view of the slot's Gram [J r]^T [J r] left in LDS by sweep(): G(a, b), a, b in 0..P (column P = r).
 struct GramView {
@@ -697,8 +708,14 @@ __device__ inline void load_scene(Ctx& c, int scene) {
 // kRows = true: the stand-alone K1 sweep; rows go to HBM, and of the Gram only its last column (J^T r and r^T r: the
 // gradient and the cost smpc_eval_batch reports) is accumulated, on the VALU — c.wave_lds is then the row staging
 // area of the critic-major store path (2 x T x P doubles per slot).
-template <int NB, int W, bool kRows, bool kVT = false>
-__device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J) {
+// need_rest (solve kernel only): called by every lane once the LAST column of the Gram — J^T r and r^T r: gradient and
+// cost — is reduced and visible in LDS; the other columns (J^T J) are formed and reduced only if it returns true in some
+// lane of the wave. A line-search sample that fails the Armijo test needs no more than that column (Ceres evaluates cost
+// and gradient there, LineSearchFunction::Evaluate), and most sweeps of a solve are such samples. c.gram_full tells
+// the caller what it got (wave-uniform). Every entry is summed in the same order whichever way it is produced.
+struct NeedAll { __device__ inline bool operator()() const { return true; } };
+template <int NB, int W, bool kRows, bool kVT = false, class NeedRest = NeedAll>
+__device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double* out_J, NeedRest need_rest = NeedRest()) {
   constexpr int P = 2 * NB;
   const auto& k = *c.kp;
   const int T = k.T, N = k.N, sl = c.sl;  // T: the batch's T = the stride of every per-step array
@@ -796,6 +813,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
     double su[4] = {0.0, 0.0, 0.0, 0.0};  // sums over valid agents of dF/du: (fx,ux) (fy,ux) (fx,uy) (fy,uy)
     double qh[4] = {0.0, 0.0, 0.0, 0.0};  // sums over pairs of F . dF/d(x, y, ux, uy), agent side
     const MathTabP mt = &k.mt;
+    const double* atab = c.atab;
     const unsigned long long* vmask = reinterpret_cast<const unsigned long long*>(c.lds + c.L.valid);
     const unsigned long long vm = vmask[tl];
     const double rvx = vb * c1, rvy = vb * s1;  // meVel, social_work:170-171
@@ -813,7 +831,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       const bool nearer = valid & (d2 < pbest);
       pbest = nearer ? d2 : pbest;
       pidx = nearer ? a : pidx;
-      const Force F = pair_force(mt, dx, dy, pvx - awx, pvy - awy);
+      const Force F = pair_force(mt, atab, dx, dy, pvx - awx, pvy - awy);
       redo |= F.special | (d2 < 1e-12);  // |diff| < 1e-6 -> diff := (1e-6, 0), :181-184, breaks the symmetry above
       const double m = valid ? 1.0 : 0.0;
       soc[0] = fma(m, F.fx, soc[0]); soc[1] = fma(m, F.fy, soc[1]);
@@ -1284,8 +1302,7 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
       }
     };
     int col_lo = 0;
-#pragma unroll
-    for (int bq = 0; bq < Q; ++bq) {  // column bq of [J r]: 2q = v_q, 2q+1 = w_q, P = r
+    auto column = [&](int bq) {  // column bq of [J r]: 2q = v_q, 2q+1 = w_q, P = r; entries 0 .. bq (upper triangle)
       double Wx, Wy, Wt, Wv;  // column bq of A M (for bq = P: b itself)
       if (bq == P) { Wx = bx; Wy = by; Wt = bt; Wv = bv; }
       else if ((bq & 1) == 0) {
@@ -1318,8 +1335,19 @@ __device__ inline GramView sweep(Ctx& c, const double* xp, double* out_r, double
         hv[cnt++] = h;
         if (cnt == kGramChunk) { flush(cnt, chunk_base, col_lo, bq); chunk_base += cnt; cnt = 0; }  // a full chunk
       }
+    };
+    // the last column first: gradient and cost, enough for a line-search sample that fails the Armijo test
+    chunk_base = P * (P + 1) / 2;
+    column(P);
+    if (cnt > 0) { flush(cnt, chunk_base, col_lo, P); cnt = 0; }
+    wave_lds_fence();
+    c.gram_full = __any(need_rest());
+    if (c.gram_full) {
+      chunk_base = 0;
+#pragma unroll
+      for (int bq = 0; bq < P; ++bq) column(bq);
+      if (cnt > 0) flush(cnt, chunk_base, col_lo, P - 1);
     }
-    if (cnt > 0) flush(cnt, chunk_base, col_lo, P);
   }
   wave_lds_fence();  // Gram visible to every lane of the slot; the cos/sin block may be rewritten by the next sweep
   SMPC_STAMP(c, 5);

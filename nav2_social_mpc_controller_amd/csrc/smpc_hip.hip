@@ -57,9 +57,12 @@ Dims make_dims(const smpc_params& p, int T, bool has_people) {
 }  // namespace
 
 namespace smpc {
-struct ProbeParams { int fn, n; const double* a; const double* b; double* o0; double* o1; MathTab mt; };
+struct ProbeParams { int fn, n; const double* a; const double* b; double* o0; double* o1; MathTab mt; AtanNodeTab an; };
 __global__ void smpc_math_probe_kernel(const ProbeParams) {
   const auto& k = *(const ProbeParams __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+  __shared__ double atab[kAtanTabDoubles];  // the LDS copy of the nodes, as in the sweep kernels
+  for (int j = threadIdx.x; j < kAtanTabDoubles; j += blockDim.x) atab[j] = k.an.v[j];
+  __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= k.n) return;
   const double a = (k.fn == 7) ? 0.0 : k.a[i], b = k.b ? k.b[i] : 0.0;
@@ -71,6 +74,7 @@ __global__ void smpc_math_probe_kernel(const ProbeParams) {
     case 3: r0 = rsqrt_pos(a); break;
     case 4: r0 = div_fast(a, b); break;
     case 5: r0 = rcp_estimate(a); break;
+    case 8: r0 = atan2_unit(&k.mt, atab, a, b); break;
     case 7: {  // a = [c4 c3 c2 c1 c0 lo hi _] per problem: the line search's bracketed root finder, trips in out1
       const double q[5] = {k.a[8 * i], k.a[8 * i + 1], k.a[8 * i + 2], k.a[8 * i + 3], k.a[8 * i + 4]};
       int trips = 0;
@@ -140,7 +144,7 @@ template <int NB> KernelFn pick_w(int W, bool eval, bool vt) {
 KernelFn pick(int nb, int W, bool eval, bool vt = false) {
 #ifdef SMPC_ONLY_NB  // development builds: one instantiation only (seconds instead of a minute to compile)
   return nb == SMPC_ONLY_NB ? pick_w<SMPC_ONLY_NB>(W, eval, vt) : nullptr;
-#endif
+#else
   switch (nb) {
     case 1: return pick_w<1>(W, eval, vt);
     case 2: return pick_w<2>(W, eval, vt);
@@ -154,6 +158,7 @@ KernelFn pick(int nb, int W, bool eval, bool vt = false) {
     case 10: return pick_w<10>(W, eval, vt);
     default: return nullptr;
   }
+#endif
 }
 
 int validate(const smpc_handle* h, const smpc_scene_batch* sb, Dims* d) {
@@ -181,6 +186,7 @@ void fill_kparams(const smpc_handle* h, const smpc_scene_batch* sb, const Dims& 
   k->e_M = d.M;
   k->hp_A = sb->N;  // set by launch() once the slot width is chosen
   smpc::fill_math_table(&k->mt);
+  smpc::fill_atan_nodes(&k->an);
 }
 
 #define SMPC_TRY_(expr) do { int _rc = (expr); if (_rc != SMPC_OK) return _rc; } while (0)
@@ -374,7 +380,8 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
   if (std::getenv("SMPC_NO_HELPERS")) k.hp_A = k.N;  // experiment knob (the LDS layout keeps the helper regions)
   // behind the slot blocks: the feasibility rows of every slot (solve) or the row staging blocks + parked sensitivities (K1)
   const size_t extra = eval ? (size_t)smpc::eval_extra_doubles(k.T, k.P, W) : (size_t)smpc::wave_extra_doubles(k.P, W);
-  const size_t shmem = ((size_t)S * L.total + extra) * sizeof(double);
+  // ... and behind those the wave's copy of the arctangent's node table
+  const size_t shmem = ((size_t)smpc::atan_tab_offset(S * L.total, (int)extra) + smpc::kAtanTabDoubles) * sizeof(double);
   if (shmem > 160 * 1024) { set_error("scene does not fit the 160 KiB LDS of one CU"); return SMPC_ERR_UNSUPPORTED; }
   if (shmem > 64 * 1024) SMPC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   if (k.B == 0) return SMPC_OK;
@@ -1066,14 +1073,15 @@ double smpc_fp64_peak_probe(smpc_handle* h, int32_t iters) {
 }
 
 int smpc_math_probe(smpc_handle* h, int32_t fn, int32_t n, const double* a, const double* b, double* out0, double* out1) {
-  if (!h || !a || !out0 || n < 0 || fn < 0 || fn > 7) { set_error("bad arguments to smpc_math_probe"); return SMPC_ERR_INVALID_ARG; }
-  if ((fn == 1 || fn == 4) && !b) { set_error("second argument array is null"); return SMPC_ERR_INVALID_ARG; }
+  if (!h || !a || !out0 || n < 0 || fn < 0 || fn > 8) { set_error("bad arguments to smpc_math_probe"); return SMPC_ERR_INVALID_ARG; }
+  if ((fn == 1 || fn == 4 || fn == 8) && !b) { set_error("second argument array is null"); return SMPC_ERR_INVALID_ARG; }
   if (fn == 2 && !out1) { set_error("out1 is null for sincos"); return SMPC_ERR_INVALID_ARG; }
   SMPC_HIP_CHECK(hipSetDevice(h->device));
   smpc::ProbeParams p;
   std::memset(&p, 0, sizeof(p));
   p.fn = fn; p.n = n;
   smpc::fill_math_table(&p.mt);
+  smpc::fill_atan_nodes(&p.an);
   Staging st(h);
   SMPC_TRY(st.up(a, (size_t)n * (fn == 7 ? 8 : 1), &p.a, h->stream));
   SMPC_TRY(st.up(b, (size_t)n, &p.b, h->stream));

@@ -428,6 +428,13 @@ __device__ inline double yaw_roundtrip(double yaw) {
 }
 
 
+// Armijo sufficient decrease of a line-search sample, the one expression both the sweep (does the
+// sample need its whole Gram?) and the state machine (is the search over?) evaluate: explicit operations, so that the two
+// sites cannot be contracted differently. A NaN value fails.
+__device__ inline bool armijo_holds(double value, double cost, double gd0, double alpha) {
+  return isfinite(value) && !(value > fma(1e-4 * gd0, alpha, cost));
+}
+
 enum Phase { PH_FETCH = 0, PH_INIT = 1, PH_LS = 2, PH_REEVAL = 3, PH_DONE = 4, PH_IDLE = 5 };
 
 // Slot-uniform LM scalars parked in LDS (offsets into the scal[] block).
@@ -459,6 +466,11 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
   c.kp = &k;
   c.L = make_layout(k.T, k.N, P, kLayoutSolve, W);
   c.ag = k.people_rec;
+  {
+    double* atab = lds_all + atan_tab_offset(S * c.L.total, wave_extra_doubles(P, W));
+    load_atan_nodes(c.kp, atab, lane);
+    c.atab = atab;
+  }
   const auto& prm = k.prm;
   const int T = k.T;
   // Everything below is derived from the lane index. It is re-derived at the top of every trip and again behind the
@@ -607,7 +619,21 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
 
     // ---------------------------------------------------------------- one sweep for every slot of the wave
     park();
-    sweep<NB, W, false, kVT>(c, xt, nullptr, nullptr);  // [J r]^T [J r] of this slot, left in LDS
+    // What the slot needs of this sweep: the whole Gram where the point can be adopted (the initial point, a sample that
+    // passes the Armijo test, a re-evaluation), its last column — cost and gradient — where the sample only feeds the
+    // line search's interpolation (the common case: 19 of a solve's 52 sweeps are adopted on the headline workload).
+    const int phase_at_sweep = R.phase;
+    auto need_rest = [&]() -> bool {
+      if (phase_at_sweep != PH_LS) return phase_at_sweep != PH_IDLE;
+      const double* gt = c.lds + c.L.gram;
+      const double* svp = c.lds + c.L.lm + P * P + 6 * P;
+      const unsigned long long slot_bits = (W == 64) ? ~0ull : (0xffffffffull << (32 * c.slot));
+      // a non-finite residual or Jacobian entry shows in this column too (a product with it is not finite): only then,
+      // and then always, the diagonal is formed as well and decides as before
+      const bool col_finite = (__ballot(c.sl <= P && !isfinite(gt[min(c.sl, P) * (P + 1) + P])) & slot_bits) == 0ull;
+      return !col_finite || armijo_holds(0.5 * gt[P * (P + 1) + P], svp[S_COST], svp[S_GD0], svp[S_CUR_X]);
+    };
+    sweep<NB, W, false, kVT>(c, xt, nullptr, nullptr, need_rest);  // [J r]^T [J r] of this slot, left in LDS
     {
       int lane_t = lane;
       asm volatile("" : "+v"(lane_t));
@@ -623,7 +649,9 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
     const double lo_q = bounded ? ((q & 1) ? prm.w_min : prm.v_min) : -1.7976931348623157e308;
     const double hi_q = bounded ? ((q & 1) ? prm.w_max : prm.v_max) : 1.7976931348623157e308;
     // usable iff every residual and Jacobian entry was finite: a non-finite one makes its diagonal Gram entry non-finite
-    const bool finite = !slot_any(c.sl <= P && !isfinite(GH.base[min(c.sl, P) * GH.ld + min(c.sl, P)]));
+    // (a sweep that stopped at the last column had every entry of that column finite, see need_rest)
+    const bool gram_full = c.gram_full;
+    const bool finite = !gram_full || !slot_any(c.sl <= P && !isfinite(GH.base[min(c.sl, P) * GH.ld + min(c.sl, P)]));
     const double val = 0.5 * GH(P, P);
     bool new_iteration = false;
 
@@ -662,6 +690,12 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
         R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_FUNCTION_TOL; R.phase = PH_DONE; return;
       }
       const double rho = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : div_fast(cost_change, sv[S_MCC]);
+      if (rho > 1e-3 && !gram_full) {
+        // never seen: a candidate that failed the Armijo test cannot be accepted (cost - value < -1e-4 g.delta <
+        // 1e-3 model_cost_change). Should rounding ever say otherwise, the point is swept again with its whole Gram.
+        R.phase = PH_REEVAL;
+        return;
+      }
       if (rho > 1e-3) {
         adopt_trial_point();
         sv[S_COST] = cand_cost;
@@ -702,7 +736,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kerne
       sv[S_CUR_V] = val; sv[S_CUR_G] = gd;
       const double alpha = sv[S_CUR_X];
       if (R.n_samples == 1) { sv[S_FIRST_V] = val; R.first_vv = R.cur_vv; }  // the full step: candidate if the search fails
-      if (R.cur_vv && !(val > sv[S_COST] + 1e-4 * sv[S_GD0] * alpha)) {
+      if (R.cur_vv && armijo_holds(val, sv[S_COST], sv[S_GD0], alpha)) {
         // Armijo satisfied: delta *= alpha; the candidate is this very point
         if (act) dl[q] = dq * alpha;
         candidate();
@@ -933,6 +967,11 @@ __global__ __launch_bounds__(64, SMPC_EVAL_MIN_WAVES(NB)) void smpc_eval_kernel(
   c.wave_lds = lds_all + (size_t)S * c.L.total;
   c.slot = slot;
   c.ag = k.people_rec;
+  {
+    double* atab = lds_all + atan_tab_offset(S * c.L.total, eval_extra_doubles(k.T, P, W));
+    load_atan_nodes(c.kp, atab, lane);
+    c.atab = atab;
+  }
 #ifdef SMPC_STAMPS
   for (int i = 0; i < 8; ++i) c.acc[i] = 0;
   for (int i = 0; i < 4; ++i) c.acc2[i] = 0;

@@ -45,7 +45,14 @@ struct MathTab {
   double log2e, ln2_hi, ln2_lo;
   double two_over_pi, pio2_hi, pio2_lo;
   double exp_min;     // arguments below this give exp = 0 after ldexp
+  double asin_c[3];   // asin(s) = s * (1 + x (a_0 + x (a_1 + x a_2))), x = s^2 <= 5.4e-4 (atan2_unit)
 };
+
+// Nodes of atan2_unit(): entry k = 0..23 holds C_k = sqrt(1 - S_k^2), A_k = asin(S_k), S_k = k / 32 and a pad (32 bytes,
+// one 16-byte and one 8-byte LDS read). The kernels that call atan2_unit() copy the table from their kernel arguments
+// into LDS once per wave; a lane indexes it by the sine of its own reduced angle.
+constexpr int kAtanNodes = 24, kAtanNodeStride = 4;
+struct AtanNodeTab { double v[kAtanNodes * kAtanNodeStride]; };
 
 typedef const MathTab SMPC_TAB_AS* MathTabP;
 
@@ -66,6 +73,42 @@ inline void fill_math_table(MathTab* t) {
   t->pio2_hi = 1.57079632679489655800;     // double(pi / 2)
   t->pio2_lo = 6.12323399573676603587e-17; // pi / 2 - pio2_hi
   t->exp_min = -745.2;
+  t->asin_c[0] = 0.16666666666785204; t->asin_c[1] = 0.07499998898949106; t->asin_c[2] = 0.04467558115827848;
+}
+
+inline void fill_atan_nodes(AtanNodeTab* n) {
+  // C_k, A_k of tools/gen_math_tables.py (60-digit arithmetic, rounded to nearest)
+  const double ca[2 * kAtanNodes] = {
+      1.0, 0.0,
+      0.9995115994824673, 0.031255088499495154,
+      0.998044963916957, 0.06254076179649139,
+      0.9955957701296244, 0.09388787510751648,
+      0.9921567416492215, 0.1253278311680654,
+      0.9877175393299442, 0.1568928710204612,
+      0.982264602843857, 0.1886163861754041,
+      0.9757809372497497, 0.22053326092083333,
+      0.9682458365518543, 0.25268025514207865,
+      0.9596345332990055, 0.2850964402527462,
+      0.9499177595981665, 0.31782370392788073,
+      0.939061200082295, 0.3509073435910811,
+      0.9270248108869579, 0.3843967744956391,
+      0.9137619698258403, 0.4183463864434681,
+      0.899218410621135, 0.4528165947449256,
+      0.8833308765689106, 0.48787514754029293,
+      0.8660254037844386, 0.5235987755982989,
+      0.8472151069828724, 0.560075306226582,
+      0.8267972847076845, 0.5974064166453502,
+      0.8046495743489833, 0.6357112854013022,
+      0.7806247497997998, 0.6751315329370317,
+      0.7545435292281023, 0.7158380602251112,
+      0.7261843774138906, 0.758040765426236,
+      0.6952686081652184, 0.8020027778036185};
+  for (int k = 0; k < kAtanNodes; ++k) {
+    n->v[kAtanNodeStride * k] = ca[2 * k];
+    n->v[kAtanNodeStride * k + 1] = ca[2 * k + 1];
+    n->v[kAtanNodeStride * k + 2] = (double)k / 32.0;
+    n->v[kAtanNodeStride * k + 3] = 0.0;
+  }
 }
 
 // ---- hardware estimates (device) and their stand-ins for the host-side checks --------------------------------------
@@ -140,6 +183,43 @@ SMPC_MATH_FN double atan2_dir(MathTabP t, double y, double x) {
   const bool swap = ay > ax, negx = x < 0.0;
   // octant: (!swap, x>=0): a | (swap, x>=0): pi/2 - a | (swap, x<0): pi/2 + a | (!swap, x<0): pi - a
   const double w = swap ? 1.0 : (negx ? 2.0 : 0.0);  // multiples of pi/2: selects on the high words of inline constants
+  a = (swap != negx) ? -a : a;
+  return copysign(fma(w, t->pio2_hi, a), y);
+}
+
+// atan2(y, x) of a UNIT vector (x^2 + y^2 = 1 up to rounding: the callers pass the cross / dot product of two unit
+// vectors), without a division and with three polynomial steps instead of twenty. After the octant reduction the
+// angle a in [0, pi/4] is known by its sine mn and its cosine mx. Node k = rint(32 mn) has sine S_k = k / 32 exactly;
+// s' = mn C_k - mx S_k = sin(a - A_k) with |a - A_k| <= 0.0226, so a = A_k + asin(s') and asin(s') = s' U(s'^2) with a
+// cubic U (relative error 2e-17 of a term below 0.023). Absolute error of the result: the rounding of mn C_k and of the
+// tabulated C_k, A_k — about 1e-16, the size of half an ulp of a result near 1 (the results span (-pi, pi]; what the
+// force needs of theta is its absolute accuracy). `nodes`: the AtanNodeTab entries (LDS in the kernels).
+// Wild arguments stay inside the table (the index is clamped); a NaN argument is dropped by the min / max as in
+// atan2_dir (the callers' other outputs carry the NaN).
+SMPC_MATH_FN double atan2_unit(MathTabP t, const double* nodes, double y, double x) {
+  const double ax = fabs(x), ay = fabs(y);
+#if defined(__HIP_DEVICE_COMPILE__)
+  double mx, mn;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+  asm("v_min_f64 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
+#else
+  const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
+#endif
+  // rint(32 mn) as the low word of mn + 1.5 * 2^47, whose unit in the last place is 1 / 32 (one addition, no conversion)
+  const double kd = mn + 211106232532992.0;
+  uint64_t kbits;
+  __builtin_memcpy(&kbits, &kd, 8);
+  uint32_t ki = (uint32_t)kbits;
+  ki = ki < (uint32_t)(kAtanNodes - 1) ? ki : (uint32_t)(kAtanNodes - 1);
+  const double* nd = nodes + kAtanNodeStride * ki;
+  const double Ck = nd[0], Ak = nd[1], Sk = nd[2];
+  const double sp = fma(-mx, Sk, mn * Ck);  // mx S_k enters exactly
+  const double xx = sp * sp;
+  double p = fma(t->asin_c[2], xx, t->asin_c[1]);
+  p = fma(p, xx, t->asin_c[0]);
+  double a = fma(sp * xx, p, sp) + Ak;  // in [0, pi/4]
+  const bool swap = ay > ax, negx = x < 0.0;
+  const double w = swap ? 1.0 : (negx ? 2.0 : 0.0);
   a = (swap != negx) ? -a : a;
   return copysign(fma(w, t->pio2_hi, a), y);
 }

@@ -11,6 +11,11 @@ void shim_atan2(const double* y, const double* x, double* o, int n) {
   smpc::MathTab t; smpc::fill_math_table(&t);
   for (int i = 0; i < n; ++i) o[i] = smpc::atan2_dir(&t, y[i], x[i]);
 }
+void shim_atan2_unit(const double* y, const double* x, double* o, int n) {
+  smpc::MathTab t; smpc::fill_math_table(&t);
+  smpc::AtanNodeTab nodes; smpc::fill_atan_nodes(&nodes);
+  for (int i = 0; i < n; ++i) o[i] = smpc::atan2_unit(&t, nodes.v, y[i], x[i]);
+}
 void shim_sincos(const double* x, double* s, double* c, int n) {
   smpc::MathTab t; smpc::fill_math_table(&t);
   for (int i = 0; i < n; ++i) smpc::sincos_tab(&t, x[i], &s[i], &c[i]);

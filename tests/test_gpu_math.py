@@ -42,6 +42,23 @@ def test_atan2_of_directions(solver):
     assert u.max() <= 2.0 and (u > 1.0).mean() < 1e-3
 
 
+def test_atan2_of_unit_vectors(solver):
+    """atan2_unit on the device (node table in LDS): the same absolute bound as on the host (tests/test_math.py)."""
+    rng = np.random.default_rng(12)
+    ang = np.concatenate([rng.uniform(-np.pi, np.pi, 600000),
+                          np.array([0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi, -np.pi / 2, -np.pi / 4]),
+                          rng.choice([-1, 1], 20000) * 10.0 ** rng.uniform(-12, -1, 20000),
+                          np.pi - 10.0 ** rng.uniform(-12, -1, 20000),
+                          np.arcsin((np.arange(48) + 0.5) / 64.0)])
+    scale = 1.0 + 5e-16 * rng.standard_normal(len(ang))
+    y, x = np.sin(ang) * scale, np.cos(ang) * scale
+    o, _ = solver.math_probe(8, y, x)
+    want = np.arctan2(y, x)
+    assert np.abs(o - want).max() <= 6e-16
+    small = np.abs(want) < 0.0156
+    assert (np.abs(o[small] - want[small]) <= 4e-15 * np.abs(want[small])).all()
+
+
 def test_sincos(solver):
     rng = np.random.default_rng(3)
     x = np.concatenate([rng.uniform(-20, 20, 400000), rng.uniform(-1e5, 1e5, 100000), np.arange(-40, 41) * (np.pi / 4)])

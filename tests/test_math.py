@@ -80,6 +80,39 @@ def test_atan2_of_directions(shim):
     assert ulps(o, np.arctan2(yk, xk)).max() <= 2.0
 
 
+def test_atan2_of_unit_vectors(shim):
+    """atan2_unit: the sweep's arctangent (cross / dot of two unit vectors): node table + cubic asin kernel, no division.
+    What the social force needs of theta is its ABSOLUTE accuracy (theta enters as B theta, results span (-pi, pi])."""
+    rng = np.random.default_rng(12)
+    ang = np.concatenate([rng.uniform(-np.pi, np.pi, 400000),
+                          np.array([0.0, np.pi / 4, np.pi / 2, 3 * np.pi / 4, np.pi, -np.pi / 2, -np.pi / 4]),
+                          rng.choice([-1, 1], 20000) * 10.0 ** rng.uniform(-12, -1, 20000),
+                          np.pi - 10.0 ** rng.uniform(-12, -1, 20000),
+                          rng.choice([-1, 1], 20000) * (np.pi / 4 + rng.choice([-1, 1], 20000) * 10.0 ** rng.uniform(-12, -2, 20000)),
+                          np.arcsin((np.arange(48) + 0.5) / 64.0)])   # the node boundaries
+    scale = 1.0 + 5e-16 * rng.standard_normal(len(ang))               # unit up to the rounding of its factors (a few ulp)
+    y, x = np.sin(ang) * scale, np.cos(ang) * scale
+    o = np.empty_like(x)
+    shim.shim_atan2_unit(ptr(y), ptr(x), ptr(o), len(x))
+    import mpmath as mp
+    mp.mp.dps = 40
+    sub = np.concatenate([np.arange(4000), np.arange(len(x) - 60100, len(x), 25)])
+    err = np.array([abs(float(mp.mpf(float(o[i])) - mp.atan2(mp.mpf(float(y[i])), mp.mpf(float(x[i]))))) for i in sub])
+    res = np.abs(o[sub])
+    # the rounding of mn C_k and of the tabulated node (1.6e-16 together) plus the roundings of the result's assembly
+    assert np.all(err <= 1.6e-16 + 0.8 * np.spacing(res))
+    want = np.arctan2(y, x)
+    assert np.abs(o - want).max() <= 6e-16   # atan2_dir on the same inputs: 4.5e-16
+    small = np.abs(want) < 0.0156   # node 0: s' = mn exactly: relatively accurate, up to the vector's own distance from unit length
+    assert (np.abs(o[small] - want[small]) <= 4e-15 * np.abs(want[small])).all()
+    # wild arguments stay inside the table (a NaN argument is dropped by the min / max like in atan2_dir: the callers'
+    # other outputs carry the NaN then)
+    bad_y = np.array([np.nan, 1e300, 0.3, -5.0]); bad_x = np.array([0.5, 1e300, np.nan, 1e-3])
+    ob = np.empty_like(bad_x)
+    shim.shim_atan2_unit(ptr(bad_y), ptr(bad_x), ptr(ob), 4)
+    assert np.isfinite(ob[3])   # (the sanitizer build of the CPU suite watches the table index of the others)
+
+
 def test_sincos(shim):
     rng = np.random.default_rng(3)
     x = np.concatenate([rng.uniform(-20, 20, 300000), rng.uniform(-1e5, 1e5, 50000),

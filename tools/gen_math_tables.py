@@ -104,3 +104,21 @@ if __name__ == "__main__":
         show(f"sin: S degree {deg} in z = r^2 (relative error of sin)", c, e)
         c, e = remez(lambda z: mp.cos(mp.sqrt(z)), list(range(deg + 1)), 0, q, lambda z: 1 / mp.cos(mp.sqrt(z)))
         show(f"cos: C degree {deg} in z = r^2 (relative error of cos)", c, e)
+
+    # atan2 of a UNIT vector (smpc_math.hpp: atan2_unit): after the octant reduction the angle a in [0, pi/4] is known by
+    # its sine mn and cosine mx. Nodes S_k = k / 32 (k = rint(32 mn) = 0..23), C_k = sqrt(1 - S_k^2), A_k = asin(S_k):
+    # s' = mn C_k - mx S_k = sin(a - A_k), |s'| <= 0.0226, and a = A_k + asin(s'), asin(s') = s' * U(x), x = s'^2.
+    xmax = mp.mpf("0.0232") ** 2
+
+    def u(x):
+        if x == 0:
+            return mp.mpf(1)
+        s = mp.sqrt(x)
+        return mp.asin(s) / s
+    for deg in (3, 4):
+        c, e = remez(u, list(range(deg + 1)), 0, xmax, lambda x: 1 / u(x))
+        show(f"asin: U degree {deg} in x = s'^2 (relative error of asin(s'))", c, e)
+    print("// atan2_unit nodes: C_k, A_k for k = 0..23")
+    for k in range(24):
+        s = mp.mpf(k) / 32
+        print(f"  {float(mp.sqrt(1 - s * s))!r}, {float(mp.asin(s))!r},")
