@@ -366,10 +366,18 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
       } else { r0 = -qb * inv2a; r1 = r0; }
       nr = 2;
     } else if (qb != 0.0) { r0 = -qc * fast_rcp(qb); nr = 1; }
-    if (nr >= 1 && !(r0 < lo || r0 > hi)) { const double v = eval_poly_reg<nc>(poly, r0); if (v < opt_v) { opt_v = v; opt_x = r0; } }
-    if (nr >= 2 && !(r1 < lo || r1 > hi)) { const double v = eval_poly_reg<nc>(poly, r1); if (v < opt_v) { opt_v = v; opt_x = r1; } }
-    if (!(lower.x < lo || lower.x > hi)) { const double v = eval_poly_reg<nc>(poly, lower.x); if (v < opt_v) { opt_v = v; opt_x = lower.x; } }
-    if (!(current.x < lo || current.x > hi)) { const double v = eval_poly_reg<nc>(poly, current.x); if (v < opt_v) { opt_v = v; opt_x = current.x; } }
+    // Candidates: the critical points and the samples themselves, each only if it lies in [lo, hi]. In a backtracking
+    // search the interval is [1e-3, 0.6] x the current step, so the samples (0, the current step, the longer previous
+    // one) never do, and of the two critical points at most the minimum: every evaluation sits behind a wave-level
+    // test (results unchanged: a candidate outside the interval was never taken).
+    // (x >= lo && x <= hi rather than the reference's !(x < lo || x > hi): a NaN candidate, which the reference evaluates
+    // to a NaN value that never wins, is simply not evaluated)
+    const bool in0 = nr >= 1 && r0 >= lo && r0 <= hi, in1 = nr >= 2 && r1 >= lo && r1 <= hi;
+    if (__any(in0)) { const double v = eval_poly_reg<nc>(poly, r0); if (in0 && v < opt_v) { opt_v = v; opt_x = r0; } }
+    if (__any(in1)) { const double v = eval_poly_reg<nc>(poly, r1); if (in1 && v < opt_v) { opt_v = v; opt_x = r1; } }
+    const bool inl = lower.x >= lo && lower.x <= hi, inc = current.x >= lo && current.x <= hi;
+    if (__any(inl)) { const double v = eval_poly_reg<nc>(poly, lower.x); if (inl && v < opt_v) { opt_v = v; opt_x = lower.x; } }
+    if (__any(inc)) { const double v = eval_poly_reg<nc>(poly, current.x); if (inc && v < opt_v) { opt_v = v; opt_x = current.x; } }
     step_size = opt_x;
     return true;
   }
@@ -402,15 +410,18 @@ __device__ inline bool interpolate_step_fast(const Sample& lower, const Sample& 
   if (vhi < opt_v) { opt_v = vhi; opt_x = hi; }
   double roots[4];
   quartic_roots_in_range_lanes(dq, lo, hi, roots);
+  // (each candidate behind a wave-level test, as in the cubic case: roots[1..3] are NaN after the one-root shortcut)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const double rt = roots[i];
-    if (!(rt < lo || rt > hi)) { const double v = eval_poly_reg<nc>(poly, rt); if (v < opt_v) { opt_v = v; opt_x = rt; } }
+    const bool in = rt >= lo && rt <= hi;
+    if (__any(in)) { const double v = eval_poly_reg<nc>(poly, rt); if (in && v < opt_v) { opt_v = v; opt_x = rt; } }
   }
   const double sx[3] = {lower.x, current.x, previous.x};
 #pragma unroll
   for (int smp = 0; smp < 3; ++smp) {
-    if (!(sx[smp] < lo || sx[smp] > hi)) { const double v = eval_poly_reg<nc>(poly, sx[smp]); if (v < opt_v) { opt_v = v; opt_x = sx[smp]; } }
+    const bool in = sx[smp] >= lo && sx[smp] <= hi;
+    if (__any(in)) { const double v = eval_poly_reg<nc>(poly, sx[smp]); if (in && v < opt_v) { opt_v = v; opt_x = sx[smp]; } }
   }
   step_size = opt_x;
   return true;
