@@ -457,17 +457,20 @@ struct LmRegs {  // slot-uniform integers / flags kept in registers
   bool step_successful, at_least_one, prev_vv, prev_gv, cur_vv, cur_gv, first_vv;
 };
 
-// waves per SIMD the solve kernel's register allocation must allow: three up to three parameter blocks (the headline
-// shapes sit at 160-168 registers; stated so that an edit cannot silently cost the third wave), two beyond
+// waves per SIMD the solve kernel's register allocation must allow: three for the two-scenes-per-wave kernels up to three
+// parameter blocks (the headline shapes sit at 160-168 registers; stated so that an edit cannot silently cost the third
+// wave, which is what overlapped launches of several streams live on), two otherwise — the one-scene-per-wave kernels
+// serve small batches (the plugin's own B = 1 call) and long horizons, whose launches take at most eight waves per CU,
+// and their helper-lane loop needs the registers (held to 168 it spilled 14)
 #ifndef SMPC_SOLVE_MIN_WAVES
-#define SMPC_SOLVE_MIN_WAVES(NB) ((NB) <= 3 ? 3 : 2)
+#define SMPC_SOLVE_MIN_WAVES(NB, W) (((NB) <= 3 && (W) == 32) ? 3 : 2)
 #endif
 // The LM vectors and matrices of a slot are spread over its lanes: lane q < P owns parameter q (its entry of x, of the
 // trial point, of the step, row q of the scaled Gram and of its Cholesky factor). One instruction then updates all P
 // entries; sums over the parameters go through a few LDS words in index order (the same order a serial loop would
 // add them in). Nothing P x P lives in registers, so the P = 8..12 instantiations do not spill.
 template <int NB, int W, bool kVT = false>
-__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB)) void smpc_solve_kernel(const KParams) {
+__global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB, W)) void smpc_solve_kernel(const KParams) {
   const auto& k = *(KParamsK)__builtin_amdgcn_kernarg_segment_ptr();
   constexpr int P = 2 * NB;
   constexpr int S = kWave / W;
