@@ -59,6 +59,8 @@ struct KParams {
   const int32_t* order;      // [B] queue order of the solve kernel (null: index order)
   int hp_A;                  // helper lanes (W = 64 kernels, see sweep()): agents the owner lane of a step walks itself;
                              // == N: no helpers. Agents hp_A .. N-1 of every step are walked by the lanes beyond the horizon
+  int full_gram;             // != 0: every sweep of a solve forms the whole Gram (SMPC_FULL_GRAM: the check that stopping at
+                             // its last column changes nothing)
   int prio_step;             // > 0: a wave whose oldest scene has made n sweeps runs at wave priority min(n / prio_step, 3)
   double* stage_rec;         // staging kernel outputs (same layouts)
   double* stage_aux;

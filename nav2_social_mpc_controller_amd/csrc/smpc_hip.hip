@@ -406,6 +406,7 @@ int launch(smpc_handle* h, bool eval, smpc::KParams& k) {
     const int two_per_simd = lone_per_cu * h->num_cu < resident ? lone_per_cu * h->num_cu : resident;
     if (grid > two_per_simd) grid = (grid >= 4 * resident) ? resident : two_per_simd;
     k.queue = h->queue;
+    k.full_gram = std::getenv("SMPC_FULL_GRAM") ? 1 : 0;  // experiment / test knob
     k.prio_step = 0;
     if (const char* v = std::getenv("SMPC_PRIO_STEP")) { const int c = std::atoi(v); if (c >= 1) k.prio_step = c; }  // experiment knob
     SMPC_HIP_CHECK(hipMemsetAsync(h->queue, 0, sizeof(int), h->stream));

@@ -639,6 +639,7 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB, W)) void smpc_solve_ke
     const int phase_at_sweep = R.phase;
     auto need_rest = [&]() -> bool {
       if (phase_at_sweep != PH_LS) return phase_at_sweep != PH_IDLE;
+      if (k.full_gram) return true;
       const double* gt = c.lds + c.L.gram;
       const double* svp = c.lds + c.L.lm + P * P + 6 * P;
       const unsigned long long slot_bits = (W == 64) ? ~0ull : (0xffffffffull << (32 * c.slot));

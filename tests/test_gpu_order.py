@@ -106,3 +106,25 @@ def test_solve_slot_width_rule():
     s.set_solve_share(1)
     with pytest.raises(SmpcError):
         s.solve_slot_width(1, 64, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,which", [(300, 8, "readme"), (4400, 8, "readme"), (160, 3, "params_yaml"), (200, 0, "readme")])
+def test_stopping_at_the_grams_last_column_changes_nothing(B, N, which, monkeypatch):
+    """A sweep forms the whole Gram only where the point can be adopted (initial point, Armijo passed, re-evaluation);
+    a line-search sample that fails the Armijo test stops at the last column (cost, gradient). Every entry is summed in
+    the same order either way, so with SMPC_FULL_GRAM=1 (every sweep forms everything, read at every launch) the
+    results are the same bit for bit: one scene per wave with helper lanes (B = 300), two scenes per wave (4400), the
+    reference's params.yaml shape (P = 10), a batch without people."""
+    from nav2_social_mpc_controller_amd.solver import BatchSolver
+
+    prm = OptimizerParams.readme() if which == "readme" else OptimizerParams.params_yaml()
+    sc = make_scenes(prm, B, max(N, 1), people_present=N > 0)
+    s = BatchSolver(prm)
+    monkeypatch.delenv("SMPC_FULL_GRAM", raising=False)
+    lazy = s.solve(sc)
+    monkeypatch.setenv("SMPC_FULL_GRAM", "1")
+    full = s.solve(sc)
+    assert lazy["evaluations"].sum() > 3 * lazy["iterations"].sum() / 2   # there are line-search samples to skip on
+    for k in lazy:
+        assert np.array_equal(lazy[k], full[k], equal_nan=True), k
