@@ -275,7 +275,8 @@ template <int D> __device__ inline double bracketed_root(const double (&p)[D + 1
 // [lo, hi] into <= 3 pieces on which q' is monotone; its <= 3 roots there cut [lo, hi] into <= 4 pieces on which q is
 // monotone. Four neighbouring lanes take one piece each (lane & 3); roots[j] is NaN where piece j holds no root.
 __device__ inline void quartic_roots_in_range_lanes(const double (&q)[5], double lo, double hi, double (&roots)[4]) {
-  const int lane = threadIdx.x & 63;
+  int lane = threadIdx.x & 63;
+  asm volatile("" : "+v"(lane));  // (the masks "r == j" stay here: hoisted out of the persistent loop they were spilled SGPR pairs)
   const int r = lane & 3, base = lane & ~3;
   const double A = 12.0 * q[0], Bq = 6.0 * q[1], C = 2.0 * q[2];
   double e0 = lo, e1 = lo;
@@ -567,6 +568,20 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB, W)) void smpc_solve_ke
 
   for (;;) {
     SMPC_STAMP(c, 6);  // LM state machine + output stage of the previous trip
+    // Like everything derived from the lane index (above), everything derived from the launch parameters is re-derived
+    // per trip, behind an opaque copy of the argument pointer: sign extensions of T and N, "N > 1", the LDS layout's
+    // offsets, ... computed once in the prologue are ~20 scalar registers live through the whole kernel — more than the
+    // file has left; they came back as v_writelane / v_readlane spill traffic (22 spilled SGPRs in <3,32>, 70 in <5,64>;
+    // now 4 and 33). A few dozen scalar instructions and cached scalar loads per trip.
+    {
+      KParamsK kp_t = c.kp;
+      asm volatile("" : "+s"(kp_t));
+      c.kp = kp_t;
+    }
+    const auto& k = *c.kp;
+    const auto& prm = k.prm;
+    const int T = k.T;
+    c.L = make_layout(k.T, k.N, P, kLayoutSolve, W);
     {
       int lane_t = lane;
       asm volatile("" : "+v"(lane_t));
@@ -809,6 +824,10 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB, W)) void smpc_solve_ke
         if (sv[S_RADIUS] <= 1e-32) { R.status = SMPC_CONVERGENCE; R.reason = SMPC_REASON_MIN_RADIUS; R.phase = PH_DONE; break; }
         ++R.iter;
         R.step_successful = false;
+        // (the column masks "q == j" / "q > j" of this block stay inside it: hoisted out of this retry loop they were two
+        // scalar registers each, 4 NB of them, spilled)
+        int ql = q;
+        asm volatile("" : "+v"(ql));
         const double radius = sv[S_RADIUS];
         const double inv_radius = div_fast(1.0, radius);  // radius stays within [1e-32, 1e16]: no scaling cases
         // row q of Hs + diag(D^2), D^2 = clamp(diag, 1e-6, 1e32) / radius: the LM strategy (A.6)
@@ -821,17 +840,17 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB, W)) void smpc_solve_ke
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-          double s_ = arow[j] + ((j == q) ? d2 : 0.0);
+          double s_ = arow[j] + ((j == ql) ? d2 : 0.0);
 #pragma unroll
           for (int kk = 0; kk < j; ++kk) s_ = fma(-Lr[kk], Lw[j * P + kk], s_);
-          if (q == j) bc[j] = s_;
+          if (ql == j) bc[j] = s_;
           wave_lds_fence();
           const double dpiv = bc[j];
           ok = ok && (dpiv > 0.0) && isfinite(dpiv);
           const double inv = rsqrt_pos(fmax(dpiv, 1e-300));  // 1 / l_jj (never used when the pivot is not positive)
           invd[j] = inv;
           Lr[j] = s_ * inv;
-          if (act && q > j) Lw[q * P + j] = Lr[j];
+          if (act && ql > j) Lw[q * P + j] = Lr[j];
           wave_lds_fence();
         }
         // forward substitution L y = gs, backward L^T z = y; the step is -z
@@ -839,19 +858,19 @@ __global__ __launch_bounds__(64, SMPC_SOLVE_MIN_WAVES(NB, W)) void smpc_solve_ke
 #pragma unroll
         for (int kk = 0; kk < P; ++kk) {
           const double yk_own = accf * invd[kk];
-          if (q == kk) { bc[P + kk] = yk_own; yq = yk_own; }
+          if (ql == kk) { bc[P + kk] = yk_own; yq = yk_own; }
           wave_lds_fence();
           const double yk = bc[P + kk];
-          accf = fma((q > kk) ? -Lr[kk] : 0.0, yk, accf);
+          accf = fma((ql > kk) ? -Lr[kk] : 0.0, yk, accf);
         }
         double accb = yq, zq = 0.0;
 #pragma unroll
         for (int kk = P - 1; kk >= 0; --kk) {
           const double zk_own = accb * invd[kk];
-          if (q == kk) { bc[2 * P + kk] = zk_own; zq = zk_own; }
+          if (ql == kk) { bc[2 * P + kk] = zk_own; zq = zk_own; }
           wave_lds_fence();
           const double zk = bc[2 * P + kk];
-          accb = fma((act && q < kk) ? -Lw[kk * P + qc] : 0.0, zk, accb);
+          accb = fma((act && ql < kk) ? -Lw[kk * P + qc] : 0.0, zk, accb);
         }
         const double stepq = act ? -zq : 0.0;
         bool valid = ok && !slot_any(act && !isfinite(stepq));
