@@ -110,7 +110,7 @@ def test_atan2_of_unit_vectors(shim):
     bad_y = np.array([np.nan, 1e300, 0.3, -5.0]); bad_x = np.array([0.5, 1e300, np.nan, 1e-3])
     ob = np.empty_like(bad_x)
     shim.shim_atan2_unit(ptr(bad_y), ptr(bad_x), ptr(ob), 4)
-    assert np.isfinite(ob[3])   # (the sanitizer build of the CPU suite watches the table index of the others)
+    assert np.isfinite(ob[3])   # (the others may come out as anything; their node index is clamped to the table by construction)
 
 
 def test_sincos(shim):
